@@ -1,0 +1,432 @@
+// Fused multi-head self-attention forward / backward for short sequences (L <= 288, head dim 64)
+// on gfx950.  Replaces torch scaled_dot_product_attention as called from nn.MultiheadAttention in
+// clipa_torch/open_clip/transformer.py:209,223-236 (softmax(q.k^T/sqrt(dh) + mask).v, dropout 0;
+// mask = None for the image tower, additive causal triu(1)*-inf for text, transformer.py:618-624).
+//
+// CLIPA's regime is "short sequence, huge batch": B*H = 65k independent heads of L <= 257 tokens.
+// One workgroup (4 waves) owns one (batch, head): K and V (fwd) or Q, K, V, dO (bwd) are DMA'd once
+// into LDS straight from the packed [tokens, 3*D] projection output (no head-major copy), and a
+// whole softmax row lives in registers, so there is no online rescaling and the [L, L] score matrix
+// never exists in HBM.
+//
+// MFMA mapping (v_mfma_f32_32x32x16_bf16): scores are computed *transposed*, S^T[key][query] =
+// K.Q^T, which leaves each lane holding 16 keys of ONE query per 32-key tile - the softmax
+// reduction is in-lane plus one cross-half shuffle - and makes P^T directly usable as the B operand
+// of O^T[d][query] = V^T.P^T.  V^T / K^T / Q^T / dO^T operands come from row-major LDS images via
+// ds_read_b64_tr_b16.  The backward pass is two sweeps (query-major for dQ, key-major for dK/dV)
+// that recompute the probabilities from per-row (max, 1/sum) statistics kept in LDS.
+#include "common.h"
+#include "clipa_hip.h"
+
+namespace {
+
+struct AttnArgs {
+  const char* q; const char* k; const char* v; long ld_qkv;   // bf16 rows, stride in elements
+  char* o; const char* o_in; const char* d_o; long ld_o;
+  char* dq; char* dk; char* dv; long ld_dqkv;
+  int B, H, L;
+  float scale;
+  int causal;
+};
+
+// chunk permutation of a 128-byte row (8 chunks of 16 B): conflict-free for both the direct
+// ds_read_b128 operand reads and the transposed ds_read_b64_tr_b16 reads (tools/lds_bank_sim.py)
+__device__ __forceinline__ int swz_u(int row) {
+  return (((row >> 1) & 1) << 2) | ((row >> 2) & 1) | (((row >> 3) & 1) << 1);
+}
+
+// DMA rows [0, LP) x 128 B of one head into a swizzled LDS image; rows >= L read zeros (SRD bound)
+__device__ __forceinline__ void dma_image(const __amdgpu_buffer_rsrc_t rs, char* img, int LP, long ld,
+                                          int wave, int lane) {
+  for (int pc = wave; pc < LP / 8; pc += 4) {
+    const int row = pc * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ swz_u(row);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(img + pc * 1024), 16,
+                                             (unsigned)(row * ld * 2 + chunk * 16), 0, 0, 0);
+  }
+}
+
+// direct operand fragment: lane -> image row (rowbase + l31), k-chunk 2*ks+hi
+__device__ __forceinline__ bf16x8 frag_direct(const char* img, int rowbase, int l31, int hi, int ks) {
+  return *(const bf16x8*)(img + (rowbase + l31) * 128 + (((2 * ks + hi) ^ swz_u(l31)) << 4));
+}
+
+// transposed operand fragment for a 16-wide reduction step: rows rowbase16 + {4hi+0..3, 8+4hi+0..3},
+// column (colbase + 16*q16 + i16) -> 8 k-slots matching the register order of a 32x32 C fragment
+__device__ __forceinline__ bf16x8 frag_trans(const char* img, int rowbase16, int colbase, int hi, int q16, int i16) {
+  const int col = colbase + 16 * q16 + 4 * (i16 & 3);
+  const int r0 = rowbase16 + 4 * hi + (i16 >> 2);
+  const int r1 = r0 + 8;
+  const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) bf16x4*)(img + r0 * 128 + (((col >> 3) ^ swz_u(r0)) << 4) + (col & 7) * 2));
+  const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) bf16x4*)(img + r1 * 128 + (((col >> 3) ^ swz_u(r1)) << 4) + (col & 7) * 2));
+  bf16x8 f;
+  f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3];
+  f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+  return f;
+}
+
+__device__ __forceinline__ bf16x8 pack_frag(const float* v) {
+  bf16x8 f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = (short)f2bf(v[i]);
+  return f;
+}
+
+// store a 32x32 fragment held as X^T[d][row] (lane: row = l31, d = 8*(r>>2)+4*hi+(r&3)) into a
+// row-major bf16 matrix: 4 consecutive d per store
+__device__ __forceinline__ void store_frag_T(char* base, long ld, long row, int col0, int hi, const f32x16& a, float mul) {
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    u32x2 w;
+    w[0] = pack2bf(a[4 * qd + 0] * mul, a[4 * qd + 1] * mul);
+    w[1] = pack2bf(a[4 * qd + 2] * mul, a[4 * qd + 3] * mul);
+    *(u32x2*)(base + (row * ld + col0 + 8 * qd + 4 * hi) * 2) = w;
+  }
+}
+
+template <int NKT>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
+  constexpr int LP = NKT * 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sV = smem + LP * 128;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5, q16 = (lane >> 4) & 1, i16 = lane & 15;
+  const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+  const size_t hoff = ((size_t)b * p.L * p.ld_qkv + (size_t)h * 64) * 2;
+  const unsigned nrec = (unsigned)((long)(p.L - 1) * p.ld_qkv * 2 + 128);
+  const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.q + hoff, nrec);
+  const __amdgpu_buffer_rsrc_t rsK = make_rsrc(p.k + hoff, nrec);
+  const __amdgpu_buffer_rsrc_t rsV = make_rsrc(p.v + hoff, nrec);
+  dma_image(rsK, sK, LP, p.ld_qkv, wave, lane);
+  dma_image(rsV, sV, LP, p.ld_qkv, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int qt = wave; qt < NKT; qt += 4) {
+    const int qg = 32 * qt + l31;
+    bf16x8 fq[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsQ, (unsigned)(qg * p.ld_qkv * 2 + (2 * ks + hi) * 16), 0, 0);
+      fq[ks] = __builtin_bit_cast(bf16x8, t);
+    }
+    f32x16 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      if (p.causal && kt > qt) continue;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(sK, 32 * kt, l31, hi, ks), fq[ks], s[kt], 0, 0, 0);
+    }
+    float mx = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * kt + 8 * (r >> 2) + 4 * hi + (r & 3);
+        const bool valid = key < p.L && (!p.causal || key <= qg);
+        const float v = valid ? s[kt][r] * p.scale : -1e30f;
+        s[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __expf(s[kt][r] - mx);
+        s[kt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (p.causal && kt > qt) continue;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        float pv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pv[e] = s[kt][8 * s2 + e];
+        const bf16x8 pf = pack_frag(pv);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans(sV, 32 * kt + 16 * s2, 32 * dt, hi, q16, i16), pf, o[dt], 0, 0, 0);
+      }
+    }
+    if (qg < p.L) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        store_frag_T(p.o, p.ld_o, (long)b * p.L + qg, h * 64 + 32 * dt, hi, o[dt], inv);
+    }
+  }
+}
+
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
+  constexpr int LP = NKT * 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sQ = smem;
+  char* sK = smem + LP * 128;
+  char* sV = smem + 2 * LP * 128;
+  char* sDO = smem + 3 * LP * 128;
+  float* sM = (float*)(smem + 4 * LP * 128);
+  float* sL = sM + LP;
+  float* sD = sL + LP;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5, q16 = (lane >> 4) & 1, i16 = lane & 15;
+  const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+  const size_t hoff = ((size_t)b * p.L * p.ld_qkv + (size_t)h * 64) * 2;
+  const size_t ooff = ((size_t)b * p.L * p.ld_o + (size_t)h * 64) * 2;
+  const unsigned nrec = (unsigned)((long)(p.L - 1) * p.ld_qkv * 2 + 128);
+  const unsigned nrec_o = (unsigned)((long)(p.L - 1) * p.ld_o * 2 + 128);
+  dma_image(make_rsrc(p.q + hoff, nrec), sQ, LP, p.ld_qkv, wave, lane);
+  dma_image(make_rsrc(p.k + hoff, nrec), sK, LP, p.ld_qkv, wave, lane);
+  dma_image(make_rsrc(p.v + hoff, nrec), sV, LP, p.ld_qkv, wave, lane);
+  dma_image(make_rsrc(p.d_o + ooff, nrec_o), sDO, LP, p.ld_o, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // D_q = sum_d dO[q][d] * O[q][d]  (= sum_k P dP), one thread per query
+  for (int qq = tid; qq < LP; qq += 256) {
+    float acc = 0.f;
+    if (qq < p.L) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float a[8], o8[8];
+        unpack8(*(const u32x4*)(sDO + qq * 128 + c * 16), a);
+        const int lc = c ^ swz_u(qq);
+        unpack8(*(const u32x4*)(p.o_in + ooff + ((size_t)qq * p.ld_o) * 2 + lc * 16), o8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += a[i] * o8[i];
+      }
+    }
+    sD[qq] = acc;
+  }
+  __syncthreads();
+
+  // ---- sweep 1: query-major, dQ --------------------------------------------------------------
+  for (int qt = wave; qt < NKT; qt += 4) {
+    const int qg = 32 * qt + l31;
+    bf16x8 fq[4], fdo[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      fq[ks] = frag_direct(sQ, 32 * qt, l31, hi, ks);
+      fdo[ks] = frag_direct(sDO, 32 * qt, l31, hi, ks);
+    }
+    f32x16 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      if (p.causal && kt > qt) continue;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(sK, 32 * kt, l31, hi, ks), fq[ks], s[kt], 0, 0, 0);
+    }
+    float mx = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * kt + 8 * (r >> 2) + 4 * hi + (r & 3);
+        const bool valid = key < p.L && (!p.causal || key <= qg);
+        const float v = valid ? s[kt][r] * p.scale : -1e30f;
+        s[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __expf(s[kt][r] - mx);
+        s[kt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (hi == 0) { sM[qg] = mx; sL[qg] = inv; }
+    const float Dq = sD[qg];
+
+    f32x16 dq[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (p.causal && kt > qt) continue;
+      f32x16 dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(sV, 32 * kt, l31, hi, ks), fdo[ks], dp, 0, 0, 0);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        float dsv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dsv[e] = s[kt][8 * s2 + e] * inv * (dp[8 * s2 + e] - Dq) * p.scale;
+        const bf16x8 dsf = pack_frag(dsv);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans(sK, 32 * kt + 16 * s2, 32 * dt, hi, q16, i16), dsf, dq[dt], 0, 0, 0);
+      }
+    }
+    if (qg < p.L) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        store_frag_T(p.dq, p.ld_dqkv, (long)b * p.L + qg, h * 64 + 32 * dt, hi, dq[dt], 1.0f);
+    }
+  }
+  __syncthreads();
+
+  // ---- sweep 2: key-major, dK and dV -----------------------------------------------------------
+  for (int kt = wave; kt < NKT; kt += 4) {
+    const int kg = 32 * kt + l31;
+    bf16x8 fk[4], fv[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      fk[ks] = frag_direct(sK, 32 * kt, l31, hi, ks);
+      fv[ks] = frag_direct(sV, 32 * kt, l31, hi, ks);
+    }
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+    for (int qt = (p.causal ? kt : 0); qt < NKT; ++qt) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(sQ, 32 * qt, l31, hi, ks), fk[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(sDO, 32 * qt, l31, hi, ks), fv[ks], dp, 0, 0, 0);
+      }
+      float pr[16], ds[16];
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int q0 = 32 * qt + 8 * rq + 4 * hi;
+        const float4 m4 = *(const float4*)(sM + q0);
+        const float4 l4 = *(const float4*)(sL + q0);
+        const float4 d4 = *(const float4*)(sD + q0);
+        const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
+        const float ll[4] = {l4.x, l4.y, l4.z, l4.w};
+        const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * rq + e;
+          const int qg = q0 + e;
+          const bool valid = kg < p.L && (!p.causal || kg <= qg);
+          const float pe = valid ? __expf(s[r] * p.scale - mm[e]) * ll[e] : 0.f;
+          pr[r] = pe;
+          ds[r] = pe * (dp[r] - dd[e]) * p.scale;
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = pack_frag(pr + 8 * s2);
+        const bf16x8 dsf = pack_frag(ds + 8 * s2);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans(sDO, 32 * qt + 16 * s2, 32 * dt, hi, q16, i16), pf, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans(sQ, 32 * qt + 16 * s2, 32 * dt, hi, q16, i16), dsf, dk[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (kg < p.L) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        store_frag_T(p.dk, p.ld_dqkv, (long)b * p.L + kg, h * 64 + 32 * dt, hi, dk[dt], 1.0f);
+        store_frag_T(p.dv, p.ld_dqkv, (long)b * p.L + kg, h * 64 + 32 * dt, hi, dv[dt], 1.0f);
+      }
+    }
+  }
+}
+
+template <int NKT>
+int launch_fwd(const AttnArgs& a, hipStream_t st) {
+  const int lds = 2 * NKT * 32 * 128;
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) { clipa_set_error("attn_fwd attr: %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
+    done = true;
+  }
+  hipLaunchKernelGGL(attn_fwd_kernel<NKT>, dim3((unsigned)(a.B * a.H)), dim3(256), lds, st, a);
+  return clipa_check_launch("attn_fwd");
+}
+template <int NKT>
+int launch_bwd(const AttnArgs& a, hipStream_t st) {
+  const int lds = 4 * NKT * 32 * 128 + 3 * NKT * 32 * 4;
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) { clipa_set_error("attn_bwd attr: %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
+    done = true;
+  }
+  hipLaunchKernelGGL(attn_bwd_kernel<NKT>, dim3((unsigned)(a.B * a.H)), dim3(256), lds, st, a);
+  return clipa_check_launch("attn_bwd");
+}
+
+int check_args(int64_t B, int64_t H, int64_t L, int64_t dh, int64_t ld_qkv, int64_t ld_o) {
+  if (dh != 64) { clipa_set_error("attention: head dim %ld unsupported (64 only)", (long)dh); return CLIPA_ERR_ARG; }
+  if (L <= 0 || L > 288) { clipa_set_error("attention: L=%ld outside (0, 288]", (long)L); return CLIPA_ERR_ARG; }
+  if (ld_qkv % 8 != 0 || ld_o % 8 != 0) { clipa_set_error("attention: row strides must be multiples of 8 elements"); return CLIPA_ERR_ARG; }
+  if (B * H <= 0 || B * H > 0x7fffffffL) { clipa_set_error("attention: bad B*H"); return CLIPA_ERR_ARG; }
+  return 0;
+}
+
+}  // namespace
+
+#define ATTN_DISPATCH(fn, a, st)                                    \
+  switch (((a).L + 31) / 32) {                                     \
+    case 1: return fn<1>(a, st); case 2: return fn<2>(a, st);      \
+    case 3: return fn<3>(a, st); case 4: return fn<4>(a, st);      \
+    case 5: return fn<5>(a, st); case 6: return fn<6>(a, st);      \
+    case 7: return fn<7>(a, st); case 8: return fn<8>(a, st);      \
+    default: return fn<9>(a, st);                                   \
+  }
+
+extern "C" int clipa_attention_fwd(const void* q, const void* k, const void* v, void* out, int64_t B,
+                                   int64_t H, int64_t L, int64_t dh, int64_t ld_qkv, int64_t ld_o,
+                                   float scale, int causal, void* stream) {
+  if (B * H == 0) return CLIPA_OK;
+  if (int rc = check_args(B, H, L, dh, ld_qkv, ld_o)) return rc;
+  AttnArgs a = {};
+  a.q = (const char*)q; a.k = (const char*)k; a.v = (const char*)v; a.ld_qkv = ld_qkv;
+  a.o = (char*)out; a.ld_o = ld_o; a.B = (int)B; a.H = (int)H; a.L = (int)L; a.scale = scale; a.causal = causal;
+  ATTN_DISPATCH(launch_fwd, a, (hipStream_t)stream)
+}
+
+extern "C" int clipa_attention_bwd(const void* q, const void* k, const void* v, const void* out,
+                                   const void* d_out, void* dq, void* dk, void* dv, int64_t B, int64_t H,
+                                   int64_t L, int64_t dh, int64_t ld_qkv, int64_t ld_o, int64_t ld_dqkv,
+                                   float scale, int causal, void* stream) {
+  if (B * H == 0) return CLIPA_OK;
+  if (int rc = check_args(B, H, L, dh, ld_qkv, ld_o)) return rc;
+  if (ld_dqkv % 8 != 0) { clipa_set_error("attention_bwd: ld_dqkv must be a multiple of 8"); return CLIPA_ERR_ARG; }
+  AttnArgs a = {};
+  a.q = (const char*)q; a.k = (const char*)k; a.v = (const char*)v; a.ld_qkv = ld_qkv;
+  a.o_in = (const char*)out; a.d_o = (const char*)d_out; a.ld_o = ld_o;
+  a.dq = (char*)dq; a.dk = (char*)dk; a.dv = (char*)dv; a.ld_dqkv = ld_dqkv;
+  a.B = (int)B; a.H = (int)H; a.L = (int)L; a.scale = scale; a.causal = causal;
+  ATTN_DISPATCH(launch_bwd, a, (hipStream_t)stream)
+}

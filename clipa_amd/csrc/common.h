@@ -1,0 +1,120 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of clipa_amd.
+// wave = 64 lanes; MFMA 32x32x16 bf16; LDS-DMA (buffer_load ... lds); ds_read_b64_tr_b16.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = 4 VGPRs (MFMA A/B operand)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;   // 4 bf16 = 2 VGPRs
+typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4;    // 16x16 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// error codes of the C ABI
+#define CLIPA_OK 0
+#define CLIPA_ERR_ARG -1
+#define CLIPA_ERR_LAUNCH -2
+
+void clipa_set_error(const char* fmt, ...);
+int clipa_check_launch(const char* what);
+
+// ---- bf16 <-> f32 -------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(unsigned short h) {
+  return __uint_as_float(((unsigned int)h) << 16);
+}
+// round-to-nearest-even; NaN stays NaN
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
+  return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+}
+__device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(v[i] << 16);
+    f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = pack2bf(f[2 * i], f[2 * i + 1]);
+  return v;
+}
+
+// ---- activations (transformer.py:37-40 QuickGELU, nn.GELU erf / tanh) ----------------------
+enum { ACT_GELU_ERF = 0, ACT_GELU_TANH = 1, ACT_QUICK_GELU = 2 };
+
+// erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution)
+__device__ __forceinline__ float fast_erf(float x) {
+  float ax = fabsf(x);
+  float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  float p = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t +
+             0.254829592f) * t;
+  float r = 1.0f - p * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float x) {
+  if (ACT == ACT_GELU_ERF) {
+    return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f));
+  } else if (ACT == ACT_GELU_TANH) {
+    float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    float e = __expf(2.0f * u);
+    float th = 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+    return 0.5f * x * (1.0f + th);
+  } else {
+    return x * __frcp_rn(1.0f + __expf(-1.702f * x));
+  }
+}
+template <int ACT>
+__device__ __forceinline__ float act_bwd(float x) {  // d act(x) / dx
+  if (ACT == ACT_GELU_ERF) {
+    float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f));
+    float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+  } else if (ACT == ACT_GELU_TANH) {
+    float x2 = x * x;
+    float u = 0.7978845608028654f * (x + 0.044715f * x * x2);
+    float e = __expf(2.0f * u);
+    float th = 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+    float du = 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x2);
+    return 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * du;
+  } else {
+    float s = __frcp_rn(1.0f + __expf(-1.702f * x));
+    return s + x * 1.702f * s * (1.0f - s);
+  }
+}
+
+// ---- wave-level reductions (64 lanes) -------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- buffer resource (SRD) for bounds-checked loads: out-of-range lanes read 0 -------------
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
+// XCD-aware bijective remap of a 1-D workgroup id: block b runs on XCD b%8; give every XCD a
+// contiguous chunk of the logical tile sequence so neighbouring tiles share one L2.
+__device__ __forceinline__ unsigned int xcd_remap(unsigned int bid, unsigned int nwg) {
+  const unsigned int q = nwg >> 3, r = nwg & 7u;
+  const unsigned int xcd = bid & 7u, idx = bid >> 3;
+  const unsigned int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

@@ -1,0 +1,425 @@
+// bf16 MFMA GEMMs for gfx950 (MI355X).
+//
+//   gemm_nt : C[M,N] = epi(alpha * A[M,K] . B[N,K]^T + bias[N])        (forward, dgrad with W^T)
+//   gemm_tn : O[R,C] = sum_m P[m,R] * Q[m,C]                           (weight gradients)
+//
+// Reference call sites these replace (clipa_torch/open_clip/transformer.py): nn.MultiheadAttention
+// in/out projection :209,:234, mlp.c_fc/c_proj :217-219, conv1 as a patch GEMM :371,:491, the final
+// projections :528-529 and model.py:254, and the logits GEMMs of loss.py:135-142 - plus the autograd
+// transposes of each.
+//
+// Structure (both kernels): 256x256 output tile, K-step 64, 8 waves (512 threads), one workgroup per
+// CU. Operand tiles are DMA'd HBM->LDS with `buffer_load_dwordx4 ... lds` (bounds-checked SRD, so
+// ragged edges read zeros) into a double-buffered 2 x 64 KiB LDS ring; tile t+1 is in flight while
+// tile t feeds v_mfma_f32_32x32x16_bf16.  The LDS image is lane-linear (DMA constraint), so bank
+// conflicts are removed by permuting the 16-byte chunks on the *source* address and applying the
+// same XOR on the read (tools/lds_bank_sim.py).  gemm_tn reads its fragments with
+// ds_read_b64_tr_b16 (hardware transpose) because the reduction index is the slow axis of both
+// operands.  Tile ids are remapped so each XCD's L2 sees a contiguous run of tiles.
+#include "common.h"
+#include "clipa_hip.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int NTHREADS = 512;
+constexpr int IMG_BYTES = 256 * 64 * 2;       // one operand image: 32 KiB
+constexpr int STAGE_BYTES = 2 * IMG_BYTES;    // A image + B image
+constexpr int EPI_STRIDE = 528;               // bytes per C-tile row in the epilogue image
+constexpr int LDS_BYTES = 256 * EPI_STRIDE;   // 135168 B >= 2 stages (131072 B)
+
+struct NTArgs {
+  const char* A; const char* B; char* C; char* C2; const float* bias; const char* aux;
+  int M, N, K;
+  long lda, ldb, ldc, ldaux;   // element strides
+  float alpha;
+  int epi, act;
+};
+
+template <int ACT>
+__device__ __forceinline__ void epi_apply(int epi, float* v, const float* a) {
+  if (epi == CLIPA_EPI_ACT) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = act_fwd<ACT>(v[i]);
+  } else {  // CLIPA_EPI_DACT
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = v[i] * act_bwd<ACT>(a[i]);
+  }
+}
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(NTArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wm = wave >> 2, wn = wave & 3;   // wave tile: 128 (m) x 64 (n)
+
+  const int tilesN = (p.N + BN - 1) / BN;
+  const int tilesM = (p.M + BM - 1) / BM;
+  const unsigned t = xcd_remap(blockIdx.x, (unsigned)(tilesM * tilesN));
+  const int tm = t / tilesN, tn = t - tm * tilesN;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int rowsA = min(BM, p.M - m0), rowsB = min(BN, p.N - n0);
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A + (size_t)m0 * p.lda * 2, (unsigned)(rowsA * p.lda * 2));
+  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B + (size_t)n0 * p.ldb * 2, (unsigned)(rowsB * p.ldb * 2));
+
+  // DMA piece pc = j*8+wave covers image rows pc*8..pc*8+7 (128 B each); lane -> (row, phys chunk).
+  unsigned voffA[4], voffB[4];
+  int kel[4];   // first k element (within a K tile) this lane fetches in piece j
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (j * 8 + wave) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    voffA[j] = (unsigned)(row * p.lda * 2 + chunk * 16);
+    voffB[j] = (unsigned)(row * p.ldb * 2 + chunk * 16);
+    kel[j] = chunk * 8;
+  }
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+
+  auto stage = [&](int buf, int k0) {
+    char* sA = smem + buf * STAGE_BYTES;
+    char* sB = sA + IMG_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int pc = j * 8 + wave;
+      // K tail (K % 64 != 0): push the lane's offset past num_records so the DMA writes zeros
+      const unsigned oob = (k0 + kel[j] >= p.K) ? 0x80000000u : 0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(sA + pc * 1024), 16, voffA[j] | oob, k0 * 2, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(sB + pc * 1024), 16, voffB[j] | oob, k0 * 2, 0, 0);
+    }
+  };
+
+  const int sw = (l31 >> 1) & 7;
+  const int rowoffA = (wm * 128 + l31) * 128;
+  const int rowoffB = (wn * 64 + l31) * 128;
+
+  const int nkt = (p.K + BK - 1) / BK;
+  stage(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // tile kt has landed for every wave; everyone is done reading buffer (kt+1)&1
+    if (kt + 1 < nkt) stage((kt + 1) & 1, (kt + 1) * BK);
+    const char* sA = smem + (kt & 1) * STAGE_BYTES;
+    const char* sB = sA + IMG_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int coff = ((2 * ks + hi) ^ sw) << 4;
+      bf16x8 fa[4], fb[2];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) fa[mi] = *(const bf16x8*)(sA + rowoffA + mi * 4096 + coff);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) fb[ni] = *(const bf16x8*)(sB + rowoffB + ni * 4096 + coff);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+    }
+  }
+
+  // D[n][m] fragment: lane holds m = l31, n = 8*(r>>2) + 4*hi + (r&3).
+  if (OUT_F32) {
+    float* C = (float*)p.C;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm * 128 + mi * 32 + l31;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn * 64 + ni * 32 + 8 * q + 4 * hi;
+          if (m < p.M && n < p.N) {
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias) b4 = *(const float4*)(p.bias + n);
+            float4 o;
+            o.x = acc[ni][mi][4 * q + 0] * p.alpha + b4.x;
+            o.y = acc[ni][mi][4 * q + 1] * p.alpha + b4.y;
+            o.z = acc[ni][mi][4 * q + 2] * p.alpha + b4.z;
+            o.w = acc[ni][mi][4 * q + 3] * p.alpha + b4.w;
+            *(float4*)(C + (size_t)m * p.ldc + n) = o;
+          }
+        }
+      }
+    return;
+  }
+
+  __syncthreads();   // staging buffers are dead; reuse LDS as the [256][256] bf16 C image
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int nl = wn * 64 + ni * 32 + 8 * q + 4 * hi;
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias && n0 + nl < p.N) b4 = *(const float4*)(p.bias + n0 + nl);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int ml = wm * 128 + mi * 32 + l31;
+        u32x2 w;
+        w[0] = pack2bf(acc[ni][mi][4 * q + 0] * p.alpha + b4.x, acc[ni][mi][4 * q + 1] * p.alpha + b4.y);
+        w[1] = pack2bf(acc[ni][mi][4 * q + 2] * p.alpha + b4.z, acc[ni][mi][4 * q + 3] * p.alpha + b4.w);
+        *(u32x2*)(smem + ml * EPI_STRIDE + nl * 2) = w;
+      }
+    }
+  __syncthreads();
+
+  const int epi = p.epi, act = p.act;
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int c = it * NTHREADS + tid;
+    const int row = c >> 5, cc = c & 31;
+    const int m = m0 + row, n = n0 + cc * 8;
+    if (m < p.M && n < p.N) {
+      u32x4 v = *(const u32x4*)(smem + row * EPI_STRIDE + cc * 16);
+      if (epi != CLIPA_EPI_NONE) {
+        float f[8], a[8];
+        unpack8(v, f);
+        if (epi == CLIPA_EPI_ADD || epi == CLIPA_EPI_DACT) {
+          const u32x4 av = *(const u32x4*)(p.aux + ((size_t)m * p.ldaux + n) * 2);
+          unpack8(av, a);
+        }
+        if (epi == CLIPA_EPI_ADD) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f[i] += a[i];
+        } else {
+          if (epi == CLIPA_EPI_ACT && p.C2) *(u32x4*)(p.C2 + ((size_t)m * p.ldc + n) * 2) = v;
+          if (act == ACT_GELU_ERF) epi_apply<ACT_GELU_ERF>(epi, f, a);
+          else if (act == ACT_GELU_TANH) epi_apply<ACT_GELU_TANH>(epi, f, a);
+          else epi_apply<ACT_QUICK_GELU>(epi, f, a);
+        }
+        v = pack8(f);
+      }
+      *(u32x4*)(p.C + ((size_t)m * p.ldc + n) * 2) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct TNArgs {
+  const char* P; const char* Q; float* O;
+  int M, R, C;
+  long ldp, ldq, ldo;
+  int slice_rows;   // multiple of 64
+};
+
+// LDS image [64 m][256 cols] bf16 (512-B rows, 32 chunks); chunk permutation per row:
+__device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 2) ^ (((row >> 2) & 1) << 1); }
+
+__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TNArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wr = wave >> 2, wc = wave & 3;   // wave tile: 128 (r) x 64 (c)
+
+  const int tilesC = (p.C + 255) / 256;
+  const int tilesR = (p.R + 255) / 256;
+  const unsigned t = xcd_remap(blockIdx.x, (unsigned)(tilesR * tilesC));
+  const int tr = t / tilesC, tc = t - tr * tilesC;
+  const int r0 = tr * 256, c0 = tc * 256;
+  const int slice = blockIdx.y;
+  const long mbeg = (long)slice * p.slice_rows;
+  const long mend = min((long)p.M, mbeg + p.slice_rows);
+  float* O = p.O + (size_t)slice * p.R * p.ldo;
+
+  // SRD base = first row of the slice, first column of the tile; rows >= M read zeros.
+  const long rows_left = p.M - mbeg;
+  auto nrec = [&](long ld, int col0) -> unsigned {
+    long b = rows_left * ld * 2 - (long)col0 * 2;
+    if (b < 0) b = 0;
+    return (unsigned)(b > 0xffffffffL ? 0xffffffffL : b);
+  };
+  const __amdgpu_buffer_rsrc_t rsP = make_rsrc(p.P + ((size_t)mbeg * p.ldp + r0) * 2, nrec(p.ldp, r0));
+  const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.Q + ((size_t)mbeg * p.ldq + c0) * 2, nrec(p.ldq, c0));
+
+  // DMA piece pc = j*8+wave covers image rows 2pc, 2pc+1 (512 B each).
+  unsigned voffP[4], voffQ[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (j * 8 + wave) * 2 + (lane >> 5);
+    const int chunk = (lane & 31) ^ tn_swz(row);
+    voffP[j] = (unsigned)(row * p.ldp * 2 + chunk * 16);
+    voffQ[j] = (unsigned)(row * p.ldq * 2 + chunk * 16);
+  }
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ri][ci][r] = 0.f;
+
+  auto stage = [&](int buf, long mrow) {   // mrow relative to mbeg
+    char* sP = smem + buf * STAGE_BYTES;
+    char* sQ = sP + IMG_BYTES;
+    const unsigned soffP = (unsigned)(mrow * p.ldp * 2), soffQ = (unsigned)(mrow * p.ldq * 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int pc = j * 8 + wave;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, LDS_PTR(sP + pc * 1024), 16, voffP[j], soffP, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, LDS_PTR(sQ + pc * 1024), 16, voffQ[j], soffQ, 0, 0);
+    }
+  };
+
+  // transpose-read addressing: lane (hi, q, i): row = ms*16 + 8*hi + 4*half + (i>>2),
+  // col = colbase + 16*q + 4*(i&3)  ->  returns (rows +0..3, col colbase+16q+i)
+  const int q16 = (lane >> 4) & 1, i16 = lane & 15;
+  const int rsub = 8 * hi + (i16 >> 2);          // + ms*16 + 4*half
+  const int csub = 16 * q16 + 4 * (i16 & 3);     // + colbase (multiple of 32)
+
+  const int nmt = (int)((mend - mbeg + 63) / 64);
+  if (nmt > 0) stage(0, 0);
+  for (int mt = 0; mt < nmt; ++mt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (mt + 1 < nmt) stage((mt + 1) & 1, (long)(mt + 1) * 64);
+    const char* sP = smem + (mt & 1) * STAGE_BYTES;
+    const char* sQ = sP + IMG_BYTES;
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms) {
+      bf16x8 fp[4], fq[2];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int row = ms * 16 + 4 * half + rsub;
+        const int swz = tn_swz(row);
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+          const int col = wr * 128 + ri * 32 + csub;
+          const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) bf16x4*)(sP + row * 512 + (((col >> 3) ^ swz) << 4) + (col & 7) * 2));
+          fp[ri][4 * half + 0] = v[0]; fp[ri][4 * half + 1] = v[1];
+          fp[ri][4 * half + 2] = v[2]; fp[ri][4 * half + 3] = v[3];
+        }
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci) {
+          const int col = wc * 64 + ci * 32 + csub;
+          const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) bf16x4*)(sQ + row * 512 + (((col >> 3) ^ swz) << 4) + (col & 7) * 2));
+          fq[ci][4 * half + 0] = v[0]; fq[ci][4 * half + 1] = v[1];
+          fq[ci][4 * half + 2] = v[2]; fq[ci][4 * half + 3] = v[3];
+        }
+      }
+#pragma unroll
+      for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+          acc[ri][ci] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fp[ri], fq[ci], acc[ri][ci], 0, 0, 0);
+    }
+  }
+
+  // D[r][c]: lane holds c = l31, r = 8*(reg>>2) + 4*hi + (reg&3)
+#pragma unroll
+  for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+      const int c = c0 + wc * 64 + ci * 32 + l31;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int r = r0 + wr * 128 + ri * 32 + 8 * (reg >> 2) + 4 * hi + (reg & 3);
+        if (r < p.R && c < p.C) O[(size_t)r * p.ldo + c] = acc[ri][ci][reg];
+      }
+    }
+}
+
+// out[i] = cast(sum_s slab[s][i]); out dtype bf16 or f32
+template <bool OUT_BF16>
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, void* __restrict__ out, long n, int S) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 a = *(const float4*)(slabs + i);
+  for (int s = 1; s < S; ++s) {
+    const float4 b = *(const float4*)(slabs + (size_t)s * n + i);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  if (OUT_BF16) {
+    u32x2 w; w[0] = pack2bf(a.x, a.y); w[1] = pack2bf(a.z, a.w);
+    *(u32x2*)((char*)out + i * 2) = w;
+  } else {
+    *(float4*)((float*)out + i) = a;
+  }
+}
+
+bool g_attr_done = false;
+int ensure_attrs() {
+  if (g_attr_done) return 0;
+  hipError_t e;
+  e = hipFuncSetAttribute((const void*)gemm_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_nt<bf16>): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
+  e = hipFuncSetAttribute((const void*)gemm_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_nt<f32>): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
+  e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+  if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_tn): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
+  g_attr_done = true;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, const float* bias,
+                             const void* aux, int64_t M, int64_t N, int64_t K, int64_t lda,
+                             int64_t ldb, int64_t ldc, int64_t ldaux, float alpha, int epi, int act,
+                             int out_f32, void* stream) {
+  if (M <= 0 || N <= 0) return CLIPA_OK;
+  if (K <= 0 || K % 8 != 0) { clipa_set_error("gemm_nt: K=%ld must be a positive multiple of 8", (long)K); return CLIPA_ERR_ARG; }
+  if (N % 8 != 0 || ldc % 8 != 0 || lda % 8 != 0 || ldb % 8 != 0) { clipa_set_error("gemm_nt: N, lda, ldb, ldc must be multiples of 8"); return CLIPA_ERR_ARG; }
+  if ((epi == CLIPA_EPI_ADD || epi == CLIPA_EPI_DACT) && (!aux || ldaux % 8 != 0)) { clipa_set_error("gemm_nt: epilogue %d needs aux with ldaux%%8==0", epi); return CLIPA_ERR_ARG; }
+  if (out_f32 && epi != CLIPA_EPI_NONE) { clipa_set_error("gemm_nt: f32 output supports epilogue NONE only"); return CLIPA_ERR_ARG; }
+  if (256 * lda * 2 >= (1L << 30) || 256 * ldb * 2 >= (1L << 30)) { clipa_set_error("gemm_nt: leading dimension too large"); return CLIPA_ERR_ARG; }
+  if (int rc = ensure_attrs()) return rc;
+  NTArgs a;
+  a.A = (const char*)A; a.B = (const char*)B; a.C = (char*)C; a.C2 = (char*)C2; a.bias = bias; a.aux = (const char*)aux;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
+  a.alpha = alpha; a.epi = epi; a.act = act;
+  const long tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  if (out_f32) hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3((unsigned)tiles), dim3(NTHREADS), LDS_BYTES, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(gemm_nt_kernel<false>, dim3((unsigned)tiles), dim3(NTHREADS), LDS_BYTES, (hipStream_t)stream, a);
+  return clipa_check_launch("gemm_nt");
+}
+
+extern "C" int64_t clipa_gemm_tn_workspace(int64_t M, int64_t R, int64_t C, int64_t* nslices) {
+  const long tiles = ((R + 255) / 256) * ((C + 255) / 256);
+  const long mt = (M + 63) / 64;
+  long S = (1024 + tiles - 1) / tiles;     // aim for ~4 workgroups per CU
+  if (S > mt) S = mt;
+  if (S > 64) S = 64;
+  if (S < 1) S = 1;
+  if (mt > 0) { const long per = (mt + S - 1) / S; S = (mt + per - 1) / per; }
+  if (nslices) *nslices = S;
+  return S * R * C * (int64_t)sizeof(float);
+}
+
+extern "C" int clipa_gemm_tn(const void* P, const void* Q, void* out, int64_t M, int64_t R, int64_t C,
+                             int64_t ldp, int64_t ldq, int out_bf16, void* workspace,
+                             int64_t workspace_bytes, void* stream) {
+  if (R <= 0 || C <= 0) return CLIPA_OK;
+  if (R % 8 != 0 || C % 8 != 0 || ldp % 8 != 0 || ldq % 8 != 0) { clipa_set_error("gemm_tn: R, C, ldp, ldq must be multiples of 8"); return CLIPA_ERR_ARG; }
+  int64_t S = 1;
+  const int64_t need = clipa_gemm_tn_workspace(M, R, C, &S);
+  if (workspace_bytes < need || !workspace) { clipa_set_error("gemm_tn: workspace %ld < %ld bytes", (long)workspace_bytes, (long)need); return CLIPA_ERR_ARG; }
+  const long mt = (M + 63) / 64;
+  const long slice_rows = ((mt + S - 1) / S) * 64;
+  if (slice_rows * ldp * 2 >= (1L << 32) - (1 << 24) || slice_rows * ldq * 2 >= (1L << 32) - (1 << 24)) { clipa_set_error("gemm_tn: slice too large for 32-bit buffer offsets"); return CLIPA_ERR_ARG; }
+  if (int rc = ensure_attrs()) return rc;
+  TNArgs a;
+  a.P = (const char*)P; a.Q = (const char*)Q; a.O = (float*)workspace;
+  a.M = (int)M; a.R = (int)R; a.C = (int)C; a.ldp = ldp; a.ldq = ldq; a.ldo = C; a.slice_rows = (int)slice_rows;
+  const long tiles = ((R + 255) / 256) * ((C + 255) / 256);
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)tiles, (unsigned)S), dim3(NTHREADS), 2 * STAGE_BYTES, (hipStream_t)stream, a);
+  if (int rc = clipa_check_launch("gemm_tn")) return rc;
+  const long n = R * C;
+  const unsigned blocks = (unsigned)((n / 4 + 255) / 256);
+  if (out_bf16) hipLaunchKernelGGL(reduce_slabs_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, out, n, (int)S);
+  else hipLaunchKernelGGL(reduce_slabs_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, out, n, (int)S);
+  return clipa_check_launch("gemm_tn_reduce");
+}

@@ -1,0 +1,293 @@
+"""Autograd glue of the MI355X engine: coarse-grained torch.autograd.Functions whose forward and
+backward are sequences of HIP launches (clipa_amd.ops).  Mirrors, per function, the reference module
+it stands in for (paths relative to /root/reference/clipa_torch):
+
+  ResBlockFn     ResidualAttentionBlock.forward            open_clip/transformer.py:238-250
+  VisionStemFn   conv1 + cls/pos + ln_pre                  open_clip/transformer.py:480-503
+  TextStemFn     token_embedding + positional_embedding    open_clip/model.py:245-247
+  HeadFn         pool + ln_post/ln_final + projection      transformer.py:509-529, model.py:251-260
+  L2NormFn       F.normalize(dim=-1)                       open_clip/model.py:240,263
+
+Activation policy: a block keeps only its bf16 input and recomputes the rest in backward (what the
+reference does with --grad-checkpointing, transformer.py:320-325), so ViT-L/16 at local batch 4096
+(806 912 tokens) fits in HBM with whole-batch GEMMs (M = 806 912) instead of micro-batches.
+"""
+import torch
+
+from . import ops
+
+bf16, f32 = torch.bfloat16, torch.float32
+
+
+class WeightCache:
+    """bf16 operand copies of the parameters ([N,K] forward form and [K,N] transposed form for the
+    input-gradient GEMMs), refreshed when the parameter's version counter changes (i.e. once per
+    optimizer step)."""
+
+    def __init__(self):
+        self._c = {}
+
+    def _get(self, p, kind, make):
+        key = (id(p), kind)
+        ver = p._version
+        ent = self._c.get(key)
+        if ent is None or ent[0] != ver or ent[1] != p.data_ptr():
+            with torch.no_grad():
+                ent = (ver, p.data_ptr(), make(p.detach()))
+            self._c[key] = ent
+        return ent[2]
+
+    def w(self, p):   # [N,K] bf16
+        return self._get(p, "w", lambda t: t if t.dtype == bf16 else ops.to_bf16(t))
+
+    def wt(self, p):  # [K,N] bf16
+        return self._get(p, "wt", ops.transpose_bf16)
+
+    def f32(self, p):  # biases / LN affine as f32 vectors
+        return self._get(p, "f32", lambda t: t if t.dtype == f32 else ops.to_f32(t))
+
+    def custom(self, p, kind, make):
+        return self._get(p, kind, make)
+
+    def clear(self):
+        self._c.clear()
+
+
+def _like_param(g, p):
+    return g if g.dtype == p.dtype else g.to(p.dtype)
+
+
+# ---------------------------------------------------------------------------------------------
+def _block_forward(x, P, cfg, keep):
+    """x [M,D] bf16. P: dict of operand tensors. Returns y and (if keep) the intermediates."""
+    B, L, H, causal, act = cfg["B"], cfg["L"], cfg["H"], cfg["causal"], cfg["act"]
+    h1 = ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"])
+    qkv = ops.gemm_nt(h1, P["w_in"], P["b_in"])
+    a = ops.attention_fwd(qkv, B, L, H, causal)
+    x1 = ops.gemm_nt(a, P["w_out"], P["b_out"], epi=ops.EPI_ADD, aux=x)
+    h2 = ops.layernorm_fwd(x1, P["ln2_w"], P["ln2_b"], cfg["eps"])
+    if keep:
+        g, hpre = ops.gemm_nt(h2, P["w_fc"], P["b_fc"], epi=ops.EPI_ACT, act=act, want_pre=True)
+    else:
+        g, hpre = ops.gemm_nt(h2, P["w_fc"], P["b_fc"], epi=ops.EPI_ACT, act=act), None
+    y = ops.gemm_nt(g, P["w_proj"], P["b_proj"], epi=ops.EPI_ADD, aux=x1)
+    if keep:
+        return y, (h1, qkv, a, x1, h2, hpre, g)
+    return y, None
+
+
+def _block_backward(x, dy, box, P, cfg):
+    """box: one-element list holding the intermediates tuple (popped so they can be freed early)."""
+    B, L, H, causal, act = cfg["B"], cfg["L"], cfg["H"], cfg["causal"], cfg["act"]
+    h1, qkv, a, x1, h2, hpre, g = box.pop()
+    dy = dy.contiguous()
+    # y = x1 + c_proj(g)
+    dh = ops.gemm_nt(dy, P["wt_proj"], epi=ops.EPI_DACT, act=act, aux=hpre)     # [M,4D]
+    d_w_proj = ops.gemm_tn(dy, g, P["dt_w_proj"])
+    d_b_proj = ops.colsum(dy)
+    del g, hpre
+    dh2 = ops.gemm_nt(dh, P["wt_fc"])                                           # [M,D]
+    d_w_fc = ops.gemm_tn(dh, h2, P["dt_w_fc"])
+    d_b_fc = ops.colsum(dh)
+    del dh, h2
+    dx1, d_ln2_w, d_ln2_b = ops.layernorm_bwd(x1, P["ln2_w"], dh2, dres=dy, eps=cfg["eps"])
+    del dh2, x1
+    # x1 = x + out_proj(a)
+    da = ops.gemm_nt(dx1, P["wt_out"])
+    d_w_out = ops.gemm_tn(dx1, a, P["dt_w_out"])
+    d_b_out = ops.colsum(dx1)
+    dqkv = ops.attention_bwd(qkv, a, da, B, L, H, causal)
+    del da, a, qkv
+    dh1 = ops.gemm_nt(dqkv, P["wt_in"])
+    d_w_in = ops.gemm_tn(dqkv, h1, P["dt_w_in"])
+    d_b_in = ops.colsum(dqkv)
+    del dqkv, h1
+    dx, d_ln1_w, d_ln1_b = ops.layernorm_bwd(x, P["ln1_w"], dh1, dres=dx1, eps=cfg["eps"])
+    return dx, (d_ln1_w, d_ln1_b, d_w_in, d_b_in, d_w_out, d_b_out, d_ln2_w, d_ln2_b, d_w_fc, d_b_fc, d_w_proj,
+                d_b_proj)
+
+
+BLOCK_PARAM_ORDER = ("ln1_w", "ln1_b", "w_in", "b_in", "w_out", "b_out", "ln2_w", "ln2_b", "w_fc", "b_fc", "w_proj",
+                     "b_proj")
+
+
+def _block_operands(params, cache):
+    ln1_w, ln1_b, w_in, b_in, w_out, b_out, ln2_w, ln2_b, w_fc, b_fc, w_proj, b_proj = params
+    return {
+        "ln1_w": cache.f32(ln1_w), "ln1_b": cache.f32(ln1_b), "ln2_w": cache.f32(ln2_w), "ln2_b": cache.f32(ln2_b),
+        "w_in": cache.w(w_in), "w_out": cache.w(w_out), "w_fc": cache.w(w_fc), "w_proj": cache.w(w_proj),
+        "wt_in": cache.wt(w_in), "wt_out": cache.wt(w_out), "wt_fc": cache.wt(w_fc), "wt_proj": cache.wt(w_proj),
+        "b_in": cache.f32(b_in), "b_out": cache.f32(b_out), "b_fc": cache.f32(b_fc), "b_proj": cache.f32(b_proj),
+        "dt_w_in": w_in.dtype, "dt_w_out": w_out.dtype, "dt_w_fc": w_fc.dtype, "dt_w_proj": w_proj.dtype,
+    }
+
+
+class ResBlockFn(torch.autograd.Function):
+    """x + MHA(LN1(x)); then + MLP(LN2(.)) on a [M, D] bf16 token matrix (transformer.py:238-250)."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, cache, *params):
+        P = _block_operands(params, cache)
+        needs_grad = any(ctx.needs_input_grad)
+        keep = needs_grad and not cfg["recompute"]
+        y, inter = _block_forward(x, P, cfg, keep)
+        ctx.cfg, ctx.cache, ctx.params = cfg, cache, params
+        if needs_grad:
+            ctx.save_for_backward(x)
+            ctx.inter = inter
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        cfg, params = ctx.cfg, ctx.params
+        P = _block_operands(params, ctx.cache)
+        box = [ctx.inter]
+        ctx.inter = None
+        if box[0] is None:
+            box[0] = _block_forward(x, P, cfg, True)[1]
+        dx, grads = _block_backward(x, dy, box, P, cfg)
+        grads = tuple(_like_param(g, p) if p.requires_grad else None for g, p in zip(grads, params))
+        return (dx, None, None) + grads
+
+
+# ---------------------------------------------------------------------------------------------
+def _conv_weight_operand(w, Kp):
+    """conv1.weight [D,3,P,P] -> bf16 [D,Kp] in (ph,pw,c) element order, zero padded to Kp."""
+    D = w.shape[0]
+    k = w.shape[1] * w.shape[2] * w.shape[3]
+    m = w.permute(0, 2, 3, 1).reshape(D, k)
+    if Kp != k:
+        m = torch.nn.functional.pad(m, (0, Kp - k))
+    return ops.to_bf16(m.contiguous())
+
+
+def _vision_stem_forward(image, P, cfg):
+    patches = ops.patchify(image, cfg["P"], cfg["Kp"], cfg["mean"], cfg["std"])
+    pe = ops.gemm_nt(patches, P["w_conv"])
+    tok = ops.assemble_tokens(pe, P["cls"], P["pos"], cfg["B"], cfg["L"])
+    x0 = ops.layernorm_fwd(tok, P["ln_w"], P["ln_b"], cfg["eps"]) if cfg["ln_pre"] else tok
+    return patches, tok, x0
+
+
+class VisionStemFn(torch.autograd.Function):
+    """uint8/float image -> normalise -> patch GEMM -> [cls; patches] + pos -> ln_pre
+    (train.py:191-197 + transformer.py:480-503)."""
+
+    @staticmethod
+    def forward(ctx, image, cfg, cache, conv_w, cls, pos, ln_w, ln_b):
+        P = VisionStemFn._operands(cfg, cache, conv_w, cls, pos, ln_w, ln_b)
+        _, _, x0 = _vision_stem_forward(image, P, cfg)
+        ctx.cfg, ctx.cache = cfg, cache
+        ctx.params = (conv_w, cls, pos, ln_w, ln_b)
+        ctx.save_for_backward(image)
+        return x0
+
+    @staticmethod
+    def _operands(cfg, cache, conv_w, cls, pos, ln_w, ln_b):
+        Kp = cfg["Kp"]
+        P = {"w_conv": cache.custom(conv_w, "conv%d" % Kp, lambda t: _conv_weight_operand(t, Kp)),
+             "cls": cache.f32(cls), "pos": cache.f32(pos)}
+        if cfg["ln_pre"]:
+            P["ln_w"], P["ln_b"] = cache.f32(ln_w), cache.f32(ln_b)
+        return P
+
+    @staticmethod
+    def backward(ctx, dx0):
+        (image,) = ctx.saved_tensors
+        cfg = ctx.cfg
+        conv_w, cls, pos, ln_w, ln_b = ctx.params
+        P = VisionStemFn._operands(cfg, ctx.cache, conv_w, cls, pos, ln_w, ln_b)
+        patches, tok, _ = _vision_stem_forward(image, P, cfg)
+        dx0 = dx0.contiguous()
+        d_ln_w = d_ln_b = None
+        if cfg["ln_pre"]:
+            dtok, d_ln_w, d_ln_b = ops.layernorm_bwd(tok, P["ln_w"], dx0, eps=cfg["eps"])
+        else:
+            dtok = dx0
+        dpatch, dcls, dpos = ops.assemble_tokens_bwd(dtok, cfg["B"], cfg["L"], need_pos=pos.requires_grad)
+        d_conv = None
+        if conv_w.requires_grad:
+            D, C, Pp, _ = conv_w.shape
+            k = C * Pp * Pp
+            dw = ops.gemm_tn(dpatch, patches, f32)[:, :k]                     # [D, (ph,pw,c)]
+            d_conv = dw.reshape(D, Pp, Pp, C).permute(0, 3, 1, 2).contiguous()
+            d_conv = _like_param(d_conv, conv_w)
+        return (None, None, None, d_conv,
+                _like_param(dcls, cls) if cls.requires_grad else None,
+                _like_param(dpos, pos) if pos.requires_grad else None,
+                _like_param(d_ln_w, ln_w) if (cfg["ln_pre"] and ln_w.requires_grad) else None,
+                _like_param(d_ln_b, ln_b) if (cfg["ln_pre"] and ln_b.requires_grad) else None)
+
+
+class TextStemFn(torch.autograd.Function):
+    """token_embedding(text).to(bf16) + positional_embedding.to(bf16) (model.py:245-247)."""
+
+    @staticmethod
+    def forward(ctx, ids, cache, table, pos):
+        x0 = ops.embed_tokens(ids, table.detach(), cache.f32(pos))
+        ctx.save_for_backward(ids)
+        ctx.params = (table, pos)
+        return x0
+
+    @staticmethod
+    def backward(ctx, dx0):
+        (ids,) = ctx.saved_tensors
+        table, pos = ctx.params
+        dtable, dpos = ops.embed_tokens_bwd(ids, dx0.contiguous(), table.shape[0], need_table=table.requires_grad,
+                                            need_pos=pos.requires_grad)
+        return (None, None,
+                _like_param(dtable, table) if table.requires_grad else None,
+                _like_param(dpos, pos) if pos.requires_grad else None)
+
+
+class HeadFn(torch.autograd.Function):
+    """pool -> LayerNorm -> @ proj, returning f32 features [B,E].  Pooling commutes with the per-token
+    LayerNorm, so LN runs on B rows instead of B*L (SURVEY 8a identity 8)."""
+
+    @staticmethod
+    def forward(ctx, x, idx, cfg, cache, ln_w, ln_b, proj):
+        B, L, mode = cfg["B"], cfg["L"], cfg["mode"]
+        pooled = ops.pool_fwd(x, B, L, mode, idx)                            # f32 [B,D]
+        y = ops.layernorm_fwd(pooled, cache.f32(ln_w), cache.f32(ln_b), cfg["eps"], out_dtype=bf16)
+        feat = ops.gemm_nt(y, cache.wt(proj), out_f32=True) if proj is not None else ops.to_f32(y)
+        ctx.cfg, ctx.cache, ctx.params = cfg, cache, (ln_w, ln_b, proj)
+        ctx.save_for_backward(pooled, y, idx if idx is not None else torch.empty(0, device=x.device))
+        ctx.has_idx = idx is not None
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        pooled, y, idx = ctx.saved_tensors
+        idx = idx if ctx.has_idx else None
+        cfg, cache = ctx.cfg, ctx.cache
+        ln_w, ln_b, proj = ctx.params
+        dfb = ops.to_bf16(dfeat.contiguous())
+        d_proj = None
+        if proj is not None:
+            dy = ops.gemm_nt(dfb, cache.w(proj))                              # [B,E] @ proj[D,E]^T -> [B,D]
+            if proj.requires_grad:
+                d_proj = _like_param(ops.gemm_tn(y, dfb, f32), proj)          # [D,E]
+        else:
+            dy = dfb
+        dpooled, d_ln_w, d_ln_b = ops.layernorm_bwd(pooled, cache.f32(ln_w), dy, eps=cfg["eps"])
+        dx = ops.pool_bwd(dpooled, cfg["B"], cfg["L"], cfg["mode"], idx)
+        return (dx, None, None, None,
+                _like_param(d_ln_w, ln_w) if ln_w.requires_grad else None,
+                _like_param(d_ln_b, ln_b) if ln_b.requires_grad else None,
+                d_proj)
+
+
+class L2NormFn(torch.autograd.Function):
+    """F.normalize(x, dim=-1), eps 1e-12 (model.py:240,263)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y, _, inv = ops.l2norm_fwd(x.contiguous())
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        return ops.l2norm_bwd(y, inv, dy.contiguous())

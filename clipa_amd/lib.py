@@ -1,0 +1,88 @@
+"""ctypes binding of libclipa_hip.so (the C ABI declared in include/clipa_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a kernel returns an error
+code, a RuntimeError is raised (reference-side convention: plain Python exceptions, e.g.
+clipa_torch/open_clip/loss.py:40,72).
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libclipa_hip.so")
+
+_c = ctypes
+_P, _I64, _I32, _F = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_float
+
+# name -> (restype, argtypes); must list every symbol of include/clipa_hip.h
+SIGNATURES = {
+    "clipa_last_error": (_c.c_char_p, []),
+    "clipa_version": (_I32, []),
+    "clipa_gemm_nt": (_I32, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I32, _I32, _I32, _P]),
+    "clipa_gemm_tn_workspace": (_I64, [_I64, _I64, _I64, _c.POINTER(_I64)]),
+    "clipa_gemm_tn": (_I32, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I32, _P, _I64, _P]),
+    "clipa_layernorm_fwd": (_I32, [_P, _P, _P, _P, _I64, _I64, _F, _I32, _I32, _P]),
+    "clipa_layernorm_bwd_workspace": (_I64, [_I64, _I64]),
+    "clipa_layernorm_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _F, _I32, _I32, _P, _I64, _P]),
+    "clipa_attention_fwd": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I32, _P]),
+    "clipa_attention_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I32, _P]),
+    "clipa_patchify": (_I32, [_P, _P, _I64, _I64, _I64, _I64, _I32, _I32, _I32, _c.POINTER(_F), _c.POINTER(_F), _P]),
+    "clipa_assemble_tokens": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
+    "clipa_assemble_tokens_bwd": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
+    "clipa_embed_tokens": (_I32, [_P, _P, _I32, _P, _P, _I64, _I64, _I64, _I64, _P]),
+    "clipa_embed_tokens_bwd": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
+    "clipa_argmax_tokens": (_I32, [_P, _P, _I64, _I64, _P]),
+    "clipa_pool_fwd": (_I32, [_P, _P, _P, _I64, _I64, _I64, _I32, _P]),
+    "clipa_pool_bwd": (_I32, [_P, _P, _P, _I64, _I64, _I64, _I32, _P]),
+    "clipa_l2norm_fwd": (_I32, [_P, _P, _P, _P, _I64, _I64, _F, _P]),
+    "clipa_l2norm_bwd": (_I32, [_P, _P, _P, _P, _I64, _I64, _P]),
+    "clipa_colsum_workspace": (_I64, [_I64, _I64]),
+    "clipa_colsum": (_I32, [_P, _P, _I64, _I64, _I64, _P, _I64, _P]),
+    "clipa_cast_to_bf16": (_I32, [_P, _I32, _P, _I64, _P]),
+    "clipa_cast_bf16_to_f32": (_I32, [_P, _P, _I64, _P]),
+    "clipa_transpose_to_bf16": (_I32, [_P, _I32, _P, _I64, _I64, _I64, _I64, _P]),
+    "clipa_ce_rows": (_I32, [_P, _I64, _I64, _I64, _I64, _F, _P, _I64, _P, _P, _P]),
+    "clipa_sum_scale": (_I32, [_P, _P, _I64, _F, _I32, _P]),
+    "clipa_adamw": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _F, _F, _F, _F, _F, _I64, _F, _P]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load (once) and return the ctypes handle. Raises if the HIP extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"clipa_amd: HIP extension {LIB_PATH} is missing - run `python -m clipa_amd.build` "
+                "(there is no CPU fallback for the product path)")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().clipa_last_error().decode("utf-8", "replace")
+
+
+def call(name, *args):
+    """Call an int-returning entry point; non-zero return code -> RuntimeError."""
+    fn = getattr(load(), name)
+    rc = fn(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (rc={rc}): {last_error()}")
+
+
+def query(name, *args):
+    """Call a value-returning entry point (workspace-size queries)."""
+    return getattr(load(), name)(*args)

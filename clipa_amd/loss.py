@@ -1,0 +1,151 @@
+"""Contrastive (InfoNCE) loss with cross-GPU feature gather, computed by the HIP engine.
+
+Drop-in for `open_clip.loss.ClipLoss` (clipa_torch/open_clip/loss.py:92-157) and its
+`gather_features` torch.distributed branch (loss.py:73-87): same constructor, same call signature
+`loss(image_features, text_features, logit_scale, output_dict=False)`, same variants
+(local_loss x gather_with_grad), same label convention (arange + B*rank, loss.py:115-126).
+
+MI355X mapping: the image and text embeddings of a rank travel as ONE fused [B, 2E] bf16 message in a
+single RCCL all-gather (torch.distributed backend "nccl" is RCCL on ROCm; xGMI underneath), issued on
+a side HIP stream so it can overlap with whatever the compute stream still has queued; the backward of
+the differentiable gather is one reduce-scatter(SUM) of the fused [W*B, 2E] gradient, which is the
+semantics of torch.distributed.nn.all_gather's backward used by the reference.  Logits, the
+row-softmax cross-entropy and all four gradient GEMMs run in libclipa_hip.so.
+"""
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from . import ops
+
+bf16, f32 = torch.bfloat16, torch.float32
+
+
+def _gather_fused(local, world_size, group=None):
+    """all-gather [B, 2E] bf16 -> [W*B, 2E] on a side stream (overlaps with queued compute)."""
+    out = torch.empty((world_size * local.shape[0], local.shape[1]), device=local.device, dtype=local.dtype)
+    if local.is_cuda:
+        cur = torch.cuda.current_stream()
+        side = _side_stream(local.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            dist.all_gather_into_tensor(out, local, group=group)
+        cur.wait_stream(side)
+        local.record_stream(side)
+        out.record_stream(side)
+    else:
+        dist.all_gather_into_tensor(out, local, group=group)
+    return out
+
+
+def _reduce_scatter_fused(full, world_size, group=None):
+    """reduce-scatter(SUM) [W*B, 2E] f32 -> [B, 2E]: backward of the differentiable all-gather."""
+    rows = full.shape[0] // world_size
+    if not full.is_cuda:   # gloo (CPU test harness) has no reduce-scatter: all-reduce and keep our slice
+        full = full.contiguous().clone()
+        dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
+        r = dist.get_rank(group)
+        return full[r * rows:(r + 1) * rows]
+    out = torch.empty((rows, full.shape[1]), device=full.device, dtype=full.dtype)
+    dist.reduce_scatter_tensor(out, full.contiguous(), op=dist.ReduceOp.SUM, group=group)
+    return out
+
+
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
+class ClipLossFn(torch.autograd.Function):
+    """(CE(logits_per_image, y) + CE(logits_per_text, y)) / 2 with logits = s * I . T^T."""
+
+    @staticmethod
+    def forward(ctx, img, txt, logit_scale, local_loss, gather_with_grad, rank, world_size, group):
+        B, E = img.shape
+        s_t = logit_scale.detach().to(f32).reshape(())
+        s = float(s_t.item())   # scalar needed as the GEMM alpha (host sync of one 4-byte value)
+        ib, tb = ops.to_bf16(img), ops.to_bf16(txt)
+        if world_size > 1:
+            fused = torch.cat([ib, tb], dim=1)
+            allf = _gather_fused(fused, world_size, group)
+            i_all, t_all = allf[:, :E], allf[:, E:]
+        else:
+            i_all, t_all = ib, tb
+        if world_size > 1 and not local_loss:
+            i_rows, t_rows, label0 = i_all, t_all, 0
+        else:
+            i_rows, t_rows, label0 = ib, tb, (B * rank if world_size > 1 else 0)
+        R = i_rows.shape[0]
+        logits_i = ops.gemm_nt(i_rows, t_all, alpha=s, out_f32=True)      # [R, W*B]
+        logits_t = ops.gemm_nt(t_rows, i_all, alpha=s, out_f32=True)
+        need_grad = any(ctx.needs_input_grad[:3])
+        gs = 0.5 / R
+        li, dli, dsi = ops.ce_rows(logits_i, label0, gs, want_grad=need_grad)
+        lt, dlt, dst = ops.ce_rows(logits_t, label0, gs, want_grad=need_grad)
+        loss = ops.sum_scale(li, gs)
+        ops.sum_scale(lt, gs, out=loss, accumulate=True)
+        if need_grad:
+            ctx.save_for_backward(dli, dlt, dsi, dst, i_rows, t_rows, i_all, t_all)
+            ctx.meta = (s, B, E, local_loss, gather_with_grad, rank, world_size, group, img.dtype, txt.dtype,
+                        logit_scale.dtype)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        dli, dlt, dsi, dst, i_rows, t_rows, i_all, t_all = ctx.saved_tensors
+        s, B, E, local_loss, gather_with_grad, rank, W, group, idt, tdt, sdt = ctx.meta
+        # d/d(rows): logits_i = s I_rows T_all^T ; logits_t = s T_rows I_all^T
+        d_i_rows = ops.gemm_nt(dli, ops.transpose_bf16(t_all), alpha=s, out_f32=True)     # [R,E]
+        d_t_rows = ops.gemm_nt(dlt, ops.transpose_bf16(i_all), alpha=s, out_f32=True)
+        # d/d(gathered columns)
+        d_t_all = ops.gemm_tn(dli, i_rows, f32)                                            # [W*B,E]
+        d_i_all = ops.gemm_tn(dlt, t_rows, f32)
+        if W == 1:
+            d_i = d_i_rows + s * d_i_all
+            d_t = d_t_rows + s * d_t_all
+        elif local_loss:
+            d_i, d_t = d_i_rows, d_t_rows
+            if gather_with_grad:
+                rs = _reduce_scatter_fused(torch.cat([d_i_all, d_t_all], dim=1) * s, W, group)
+                d_i = d_i + rs[:, :E]
+                d_t = d_t + rs[:, E:]
+        else:
+            # rows are the gathered features themselves: every term is a gradient w.r.t. the gather
+            full = torch.cat([d_i_rows + s * d_i_all, d_t_rows + s * d_t_all], dim=1)
+            if gather_with_grad:
+                rs = _reduce_scatter_fused(full, W, group)
+            else:
+                rs = full[rank * B:(rank + 1) * B]      # only the re-inserted local slice carries grad
+            d_i, d_t = rs[:, :E], rs[:, E:]
+        d_s = (ops.sum_scale(dsi, 1.0 / s) + ops.sum_scale(dst, 1.0 / s)).reshape(())
+        g = dloss.to(f32)
+        return ((d_i * g).to(idt), (d_t * g).to(tdt), (d_s * g).to(sdt), None, None, None, None, None)
+
+
+class ClipLoss(nn.Module):
+    """Same constructor / call contract as open_clip.loss.ClipLoss (loss.py:92-157)."""
+
+    def __init__(self, local_loss=False, gather_with_grad=False, cache_labels=False, rank=0, world_size=1,
+                 use_horovod=False, group=None):
+        super().__init__()
+        if use_horovod:
+            raise NotImplementedError("clipa_amd: horovod is outside the MI355X path (RCCL via torch.distributed)")
+        self.local_loss = local_loss
+        self.gather_with_grad = gather_with_grad
+        self.cache_labels = cache_labels     # labels are implicit (arange + offset) in the CE kernel
+        self.rank = rank
+        self.world_size = world_size
+        self.use_horovod = use_horovod
+        self.group = group
+
+    def forward(self, image_features, text_features, logit_scale, output_dict=False):
+        if not torch.is_tensor(logit_scale):
+            logit_scale = torch.tensor(float(logit_scale), device=image_features.device)
+        total_loss = ClipLossFn.apply(image_features.float(), text_features.float(), logit_scale, self.local_loss,
+                                      self.gather_with_grad, self.rank, self.world_size, self.group)
+        return {"contrastive_loss": total_loss} if output_dict else total_loss

@@ -1,0 +1,318 @@
+"""Tensor-level wrappers over the C ABI: argument checking, output / workspace allocation with torch,
+current-stream plumbing.  No arithmetic happens here - every op below is one or two HIP launches.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import lib
+
+EPI_NONE, EPI_ACT, EPI_ADD, EPI_DACT = 0, 1, 2, 3
+ACT_GELU_ERF, ACT_GELU_TANH, ACT_QUICK_GELU = 0, 1, 2
+DT_U8, DT_BF16, DT_F32 = 0, 1, 2
+POOL_FIRST, POOL_LAST, POOL_INDEX, POOL_MEAN_ALL, POOL_MEAN_PATCH = 0, 1, 2, 3, 4
+
+bf16 = torch.bfloat16
+f32 = torch.float32
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype, name, dims=None):
+    if not t.is_cuda:
+        raise RuntimeError(f"clipa_amd.ops: {name} must live on the GPU (no CPU fallback); got {t.device}")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"clipa_amd.ops: {name} must be {dtype}, got {t.dtype}")
+    if dims is not None and t.dim() != dims:
+        raise RuntimeError(f"clipa_amd.ops: {name} must be {dims}-D, got shape {tuple(t.shape)}")
+    if t.dim() > 0 and t.stride(-1) != 1 and t.shape[-1] != 1:
+        raise RuntimeError(f"clipa_amd.ops: {name} must be contiguous in its last dim")
+
+
+def _rowmajor(t):
+    """Accept [rows, cols] views with unit column stride; return (tensor, ld)."""
+    if t.stride(-1) != 1:
+        t = t.contiguous()
+    return t, t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def gemm_nt(a, b, bias=None, *, epi=EPI_NONE, act=ACT_GELU_ERF, aux=None, alpha=1.0, out_f32=False,
+            want_pre=False, out=None):
+    """C[M,N] = epi(alpha * a[M,K] @ b[N,K]^T + bias). a, b bf16; bias f32 [N]."""
+    _chk(a, bf16, "a", 2)
+    _chk(b, bf16, "b", 2)
+    a, lda = _rowmajor(a)
+    b, ldb = _rowmajor(b)
+    M, K = a.shape
+    N, Kb = b.shape
+    if K != Kb:
+        raise RuntimeError(f"gemm_nt: K mismatch {K} vs {Kb}")
+    if bias is not None:
+        _chk(bias, f32, "bias", 1)
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=f32 if out_f32 else bf16)
+    ldc = out.stride(0) if M > 1 else N
+    pre = torch.empty((M, N), device=a.device, dtype=bf16) if want_pre else None
+    ldaux = 0
+    if aux is not None:
+        _chk(aux, bf16, "aux", 2)
+        aux, ldaux = _rowmajor(aux)
+    lib.call("clipa_gemm_nt", _p(a), _p(b), _p(out), _p(pre), _p(bias), _p(aux), M, N, K, lda, ldb, ldc, ldaux,
+             float(alpha), epi, act, 1 if out_f32 else 0, _stream())
+    return (out, pre) if want_pre else out
+
+
+def gemm_tn(p, q, out_dtype=f32):
+    """out[R,C] = p[M,R]^T @ q[M,C]; p, q bf16."""
+    _chk(p, bf16, "p", 2)
+    _chk(q, bf16, "q", 2)
+    p, ldp = _rowmajor(p)
+    q, ldq = _rowmajor(q)
+    M, R = p.shape
+    M2, C = q.shape
+    if M != M2:
+        raise RuntimeError(f"gemm_tn: M mismatch {M} vs {M2}")
+    ns = ctypes.c_int64(0)
+    wsb = lib.query("clipa_gemm_tn_workspace", M, R, C, ctypes.byref(ns))
+    ws = torch.empty(max(wsb, 4) // 4, device=p.device, dtype=f32)
+    out = torch.empty((R, C), device=p.device, dtype=out_dtype)
+    lib.call("clipa_gemm_tn", _p(p), _p(q), _p(out), M, R, C, ldp, ldq, 1 if out_dtype == bf16 else 0, _p(ws),
+             wsb, _stream())
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=None):
+    _chk(gamma, f32, "gamma", 1)
+    _chk(beta, f32, "beta", 1)
+    x = x.contiguous()
+    D = x.shape[-1]
+    rows = x.numel() // D
+    out_dtype = out_dtype or x.dtype
+    y = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+    lib.call("clipa_layernorm_fwd", _p(x), _p(gamma), _p(beta), _p(y), rows, D, float(eps),
+             int(x.dtype == f32), int(out_dtype == f32), _stream())
+    return y
+
+
+def layernorm_bwd(x, gamma, dy, dres=None, eps=1e-5):
+    """Returns dx (dtype of x, + dres if given), dgamma, dbeta (f32)."""
+    x = x.contiguous()
+    dy = dy.contiguous()
+    D = x.shape[-1]
+    rows = x.numel() // D
+    wsb = lib.query("clipa_layernorm_bwd_workspace", rows, D)
+    ws = torch.empty(max(wsb, 4) // 4, device=x.device, dtype=f32)
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(D, device=x.device, dtype=f32)
+    dbeta = torch.empty(D, device=x.device, dtype=f32)
+    if dres is not None:
+        dres = dres.contiguous()
+        if dres.dtype != x.dtype:
+            raise RuntimeError("layernorm_bwd: dres dtype must match x")
+    lib.call("clipa_layernorm_bwd", _p(x), _p(gamma), _p(dy), _p(dres), _p(dx), _p(dgamma), _p(dbeta), rows, D,
+             float(eps), int(x.dtype == f32), int(dy.dtype == f32), _p(ws), wsb, _stream())
+    return dx, dgamma, dbeta
+
+
+def attention_fwd(qkv, B, L, H, causal):
+    """qkv [B*L, 3*H*64] bf16 (q | k | v column blocks) -> out [B*L, H*64] bf16."""
+    _chk(qkv, bf16, "qkv", 2)
+    D = qkv.shape[1] // 3
+    dh = D // H
+    out = torch.empty((B * L, D), device=qkv.device, dtype=bf16)
+    base = qkv.data_ptr()
+    ld = qkv.stride(0)
+    lib.call("clipa_attention_fwd", ctypes.c_void_p(base), ctypes.c_void_p(base + 2 * D), ctypes.c_void_p(base + 4 * D),
+             _p(out), B, H, L, dh, ld, D, 1.0 / math.sqrt(dh), int(causal), _stream())
+    return out
+
+
+def attention_bwd(qkv, out, dout, B, L, H, causal):
+    _chk(qkv, bf16, "qkv", 2)
+    _chk(out, bf16, "out", 2)
+    _chk(dout, bf16, "dout", 2)
+    dout = dout.contiguous()
+    D = qkv.shape[1] // 3
+    dh = D // H
+    dqkv = torch.empty_like(qkv)
+    base, dbase = qkv.data_ptr(), dqkv.data_ptr()
+    lib.call("clipa_attention_bwd", ctypes.c_void_p(base), ctypes.c_void_p(base + 2 * D), ctypes.c_void_p(base + 4 * D),
+             _p(out), _p(dout), ctypes.c_void_p(dbase), ctypes.c_void_p(dbase + 2 * D), ctypes.c_void_p(dbase + 4 * D),
+             B, H, L, dh, qkv.stride(0), D, dqkv.stride(0), 1.0 / math.sqrt(dh), int(causal), _stream())
+    return dqkv
+
+
+def patchify(img, P, Kp, mean=None, std=None):
+    """img [B,3,S,S] (NCHW or channels_last memory), u8 / bf16 / f32 -> bf16 [B*(S//P)^2, Kp]."""
+    if not img.is_cuda:
+        raise RuntimeError("patchify: image must be on the GPU")
+    B, C, S, S2 = img.shape
+    if C != 3 or S != S2:
+        raise RuntimeError(f"patchify: expected [B,3,S,S], got {tuple(img.shape)}")
+    if img.is_contiguous():
+        nhwc = 0
+    elif img.is_contiguous(memory_format=torch.channels_last):
+        nhwc = 1
+    else:
+        img, nhwc = img.contiguous(), 0
+    dt = {torch.uint8: DT_U8, bf16: DT_BF16, f32: DT_F32}.get(img.dtype)
+    if dt is None:
+        raise RuntimeError(f"patchify: unsupported image dtype {img.dtype}")
+    g = S // P
+    out = torch.empty((B * g * g, Kp), device=img.device, dtype=bf16)
+    normalize = mean is not None
+    m3 = (ctypes.c_float * 3)(*([float(v) for v in mean] if normalize else [0, 0, 0]))
+    s3 = (ctypes.c_float * 3)(*([float(v) for v in std] if normalize else [1, 1, 1]))
+    lib.call("clipa_patchify", _p(img), _p(out), B, S, P, Kp, dt, nhwc, int(normalize), m3, s3, _stream())
+    return out
+
+
+def assemble_tokens(patch, cls, pos, B, L):
+    D = patch.shape[1]
+    tok = torch.empty((B * L, D), device=patch.device, dtype=bf16)
+    lib.call("clipa_assemble_tokens", _p(patch), _p(cls), _p(pos), _p(tok), B, L, D, _stream())
+    return tok
+
+
+def assemble_tokens_bwd(dtok, B, L, need_pos=True):
+    D = dtok.shape[1]
+    dtok = dtok.contiguous()
+    dpatch = torch.empty((B * (L - 1), D), device=dtok.device, dtype=bf16)
+    dcls = torch.empty(D, device=dtok.device, dtype=f32)
+    dpos = torch.empty((L, D), device=dtok.device, dtype=f32) if need_pos else None
+    lib.call("clipa_assemble_tokens_bwd", _p(dtok), _p(dpatch), _p(dcls), _p(dpos), B, L, D, _stream())
+    return dpatch, dcls, dpos
+
+
+def embed_tokens(ids, table, pos):
+    _chk(ids, torch.int64, "ids", 2)
+    _chk(pos, f32, "pos", 2)
+    ids = ids.contiguous()
+    B, T = ids.shape
+    V, D = table.shape
+    out = torch.empty((B * T, D), device=ids.device, dtype=bf16)
+    lib.call("clipa_embed_tokens", _p(ids), _p(table.contiguous()), int(table.dtype == bf16), _p(pos.contiguous()), _p(out),
+             B, T, D, V, _stream())
+    return out
+
+
+def embed_tokens_bwd(ids, dx, vocab, need_table=True, need_pos=True):
+    ids = ids.contiguous()
+    B, T = ids.shape
+    D = dx.shape[1]
+    dx = dx.contiguous()
+    dtable = torch.empty((vocab, D), device=dx.device, dtype=f32) if need_table else None
+    dpos = torch.empty((T, D), device=dx.device, dtype=f32) if need_pos else None
+    lib.call("clipa_embed_tokens_bwd", _p(ids), _p(dx), _p(dtable), _p(dpos), B, T, D, vocab, _stream())
+    return dtable, dpos
+
+
+def argmax_tokens(ids):
+    ids = ids.contiguous()
+    B, T = ids.shape
+    out = torch.empty(B, device=ids.device, dtype=torch.int32)
+    lib.call("clipa_argmax_tokens", _p(ids), _p(out), B, T, _stream())
+    return out
+
+
+def pool_fwd(x, B, L, mode, idx=None):
+    D = x.shape[-1]
+    out = torch.empty((B, D), device=x.device, dtype=f32)
+    lib.call("clipa_pool_fwd", _p(x), _p(idx), _p(out), B, L, D, mode, _stream())
+    return out
+
+
+def pool_bwd(dout, B, L, mode, idx=None):
+    D = dout.shape[-1]
+    dx = torch.empty((B * L, D), device=dout.device, dtype=bf16)
+    lib.call("clipa_pool_bwd", _p(dout.contiguous()), _p(idx), _p(dx), B, L, D, mode, _stream())
+    return dx
+
+
+def l2norm_fwd(x, eps=1e-12, want_bf16=False):
+    x = x.contiguous()
+    rows, E = x.shape
+    y = torch.empty_like(x)
+    ybf = torch.empty((rows, E), device=x.device, dtype=bf16) if want_bf16 else None
+    inv = torch.empty(rows, device=x.device, dtype=f32)
+    lib.call("clipa_l2norm_fwd", _p(x), _p(y), _p(ybf), _p(inv), rows, E, float(eps), _stream())
+    return y, ybf, inv
+
+
+def l2norm_bwd(y, inv, dy):
+    rows, E = y.shape
+    dx = torch.empty_like(y)
+    lib.call("clipa_l2norm_bwd", _p(y), _p(inv), _p(dy.contiguous()), _p(dx), rows, E, _stream())
+    return dx
+
+
+def colsum(dy):
+    _chk(dy, bf16, "dy", 2)
+    dy, ld = _rowmajor(dy)
+    M, N = dy.shape
+    wsb = lib.query("clipa_colsum_workspace", M, N)
+    ws = torch.empty(max(wsb, 4) // 4, device=dy.device, dtype=f32)
+    out = torch.empty(N, device=dy.device, dtype=f32)
+    lib.call("clipa_colsum", _p(dy), _p(out), M, N, ld, _p(ws), wsb, _stream())
+    return out
+
+
+def to_bf16(t):
+    """Flat cast f32/bf16 -> new bf16 tensor (weights are re-cast once per optimizer step)."""
+    t = t.contiguous()
+    if t.dtype not in (f32, bf16):
+        raise RuntimeError(f"to_bf16: unsupported dtype {t.dtype}")
+    out = torch.empty(t.shape, device=t.device, dtype=bf16)
+    lib.call("clipa_cast_to_bf16", _p(t), int(t.dtype == f32), _p(out), t.numel(), _stream())
+    return out
+
+
+def to_f32(t):
+    t = t.contiguous()
+    if t.dtype == f32:
+        return t
+    out = torch.empty(t.shape, device=t.device, dtype=f32)
+    lib.call("clipa_cast_bf16_to_f32", _p(t), _p(out), t.numel(), _stream())
+    return out
+
+
+def transpose_bf16(t):
+    """[R,C] f32/bf16 -> [C,R] bf16 (used for W^T operands)."""
+    t, ldi = _rowmajor(t)
+    R, C = t.shape
+    out = torch.empty((C, R), device=t.device, dtype=bf16)
+    lib.call("clipa_transpose_to_bf16", _p(t), int(t.dtype == f32), _p(out), R, C, ldi, R, _stream())
+    return out
+
+
+def ce_rows(logits, label0, gscale, want_grad=True):
+    """Row-wise CE with labels label0 + row. Returns loss_rows f32 [R], dlogits bf16 [R,N] | None, dscale_rows."""
+    _chk(logits, f32, "logits", 2)
+    R, N = logits.shape
+    loss_rows = torch.empty(R, device=logits.device, dtype=f32)
+    dscale_rows = torch.empty(R, device=logits.device, dtype=f32)
+    dl = torch.empty((R, N), device=logits.device, dtype=bf16) if want_grad else None
+    lib.call("clipa_ce_rows", _p(logits), R, N, logits.stride(0), label0, float(gscale), _p(dl), N, _p(loss_rows),
+             _p(dscale_rows), _stream())
+    return loss_rows, dl, dscale_rows
+
+
+def sum_scale(x, scale, out=None, accumulate=False):
+    x = x.contiguous()
+    if out is None:
+        out = torch.empty((), device=x.device, dtype=f32)
+    lib.call("clipa_sum_scale", _p(x), _p(out), x.numel(), float(scale), int(accumulate), _stream())
+    return out
+
+
+def adamw_(param, grad, exp_avg, exp_avg_sq, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    lib.call("clipa_adamw", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), int(param.dtype == f32),
+             int(grad.dtype == f32), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+             float(grad_scale), _stream())

@@ -1,0 +1,128 @@
+/* clipa_hip.h - C ABI of libclipa_hip.so, the MI355X (gfx950) compute engine behind the open_clip
+ * model/loss API of UCSC-VLAA/CLIPA (clipa_torch).
+ *
+ * The reference has no FFI: its hot path is torch ops called from open_clip/{transformer,model,loss}.py.
+ * Each entry point below replaces the torch op(s) at the cited reference lines (paths relative to
+ * /root/reference/clipa_torch).  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch-allocated); no hidden
+ *     allocations, no implicit synchronisation; `stream` is a hipStream_t;
+ *   - "bf16" buffers are raw uint16 bfloat16; matrices are row-major with element strides `ld*`;
+ *   - return 0 on success, negative on error (never throws); clipa_last_error() gives the message;
+ *   - re-entrant: may be called from PyTorch's autograd worker thread.
+ */
+#ifndef CLIPA_HIP_H
+#define CLIPA_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* epilogues of clipa_gemm_nt */
+#define CLIPA_EPI_NONE 0 /* C = bf16(alpha*acc + bias)                                        */
+#define CLIPA_EPI_ACT 1  /* C = act(v), optional C2 = v (pre-activation, for the backward)    */
+#define CLIPA_EPI_ADD 2  /* C = v + aux            (residual add, transformer.py:248-249)     */
+#define CLIPA_EPI_DACT 3 /* C = v * act'(aux)      (activation backward)                      */
+/* activations: nn.GELU(approximate='none'|'tanh') (model.py:128-129), QuickGELU (transformer.py:37-40) */
+#define CLIPA_ACT_GELU_ERF 0
+#define CLIPA_ACT_GELU_TANH 1
+#define CLIPA_ACT_QUICK_GELU 2
+/* input dtypes of clipa_patchify */
+#define CLIPA_DT_U8 0
+#define CLIPA_DT_BF16 1
+#define CLIPA_DT_F32 2
+/* pooling modes (transformer.py:472-478, model.py:254-260) */
+#define CLIPA_POOL_FIRST 0      /* x[:,0]  (cls token / big_vision_tok)          */
+#define CLIPA_POOL_LAST 1       /* x[:,-1] (big_vision_last)                      */
+#define CLIPA_POOL_INDEX 2      /* x[b, idx[b]] (EOT row, text.argmax(-1))        */
+#define CLIPA_POOL_MEAN_ALL 3   /* x.mean(1) incl. cls (open_clip GAP)            */
+#define CLIPA_POOL_MEAN_PATCH 4 /* x[:,1:].mean(1) (big_vision_gap)               */
+
+const char* clipa_last_error(void);
+int clipa_version(void);
+
+/* C[M,N] = epi(alpha * A[M,K] . B[N,K]^T + bias[N]); A,B bf16; C bf16 (or f32 when out_f32, epi NONE).
+ * Replaces nn.Linear / packed in-proj / out-proj / conv1-as-GEMM / `@ proj` forward and, with B = W^T,
+ * their input gradients: transformer.py:209,217-219,234,371,491,528-529; model.py:254; loss.py:135-142.
+ * K % 8 == 0; N, lda, ldb, ldc, ldaux % 8 == 0. */
+int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux,
+                  int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldaux,
+                  float alpha, int epi, int act, int out_f32, void* stream);
+
+/* out[R,C] = sum_m P[m,R] * Q[m,C]  (weight gradients dW = dY^T . X of the same layers; also the
+ * gathered-feature gradients of loss.py:135-139).  out is f32 or bf16. workspace: split-M partial slabs. */
+int64_t clipa_gemm_tn_workspace(int64_t M, int64_t R, int64_t C, int64_t* nslices);
+int clipa_gemm_tn(const void* P, const void* Q, void* out, int64_t M, int64_t R, int64_t C, int64_t ldp,
+                  int64_t ldq, int out_bf16, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* F.layer_norm over the last dim, eps inside sqrt, affine (transformer.py:19-34). x/dx share a dtype
+ * (x_f32), y/dy share a dtype (y_f32). bwd: dx = LN'(dy) [+ dres]; dgamma, dbeta f32 [D]. */
+int clipa_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, int64_t rows,
+                        int64_t D, float eps, int x_f32, int y_f32, void* stream);
+int64_t clipa_layernorm_bwd_workspace(int64_t rows, int64_t D);
+int clipa_layernorm_bwd(const void* x, const float* gamma, const void* dy, const void* dres, void* dx,
+                        float* dgamma, float* dbeta, int64_t rows, int64_t D, float eps, int x_f32,
+                        int y_f32, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* softmax(q.k^T * scale + mask).v per (batch, head); q/k/v are column blocks of the packed projection
+ * output (row stride ld_qkv), out is [B*L, H*dh] (row stride ld_o). causal = additive triu(1)*-inf mask.
+ * Replaces F.scaled_dot_product_attention inside nn.MultiheadAttention (transformer.py:223-236). */
+int clipa_attention_fwd(const void* q, const void* k, const void* v, void* out, int64_t B, int64_t H,
+                        int64_t L, int64_t dh, int64_t ld_qkv, int64_t ld_o, float scale, int causal,
+                        void* stream);
+int clipa_attention_bwd(const void* q, const void* k, const void* v, const void* out, const void* d_out,
+                        void* dq, void* dk, void* dv, int64_t B, int64_t H, int64_t L, int64_t dh,
+                        int64_t ld_qkv, int64_t ld_o, int64_t ld_dqkv, float scale, int causal,
+                        void* stream);
+
+/* image [B,3,S,S] (or NHWC) u8/bf16/f32 -> bf16 patch matrix [B*(S/P)^2, Kp], elements in (ph,pw,c)
+ * order, optional (x/255 - mean)/std (train.py:191-197 + conv1 im2col, transformer.py:371,491-493). */
+int clipa_patchify(const void* img, void* out, int64_t B, int64_t S, int64_t P, int64_t Kp, int in_dtype,
+                   int nhwc, int normalize, const float* mean3, const float* std3, void* stream);
+/* cat(class_embedding) + positional_embedding (transformer.py:496-499) and its gradient. */
+int clipa_assemble_tokens(const void* patch, const float* cls, const float* pos, void* tokens, int64_t B,
+                          int64_t L, int64_t D, void* stream);
+int clipa_assemble_tokens_bwd(const void* dtokens, void* dpatch, float* dcls, float* dpos, int64_t B,
+                              int64_t L, int64_t D, void* stream);
+/* token_embedding(text) + positional_embedding (model.py:245-247) and gradients (dense f32 table grad). */
+int clipa_embed_tokens(const int64_t* ids, const void* table, int table_bf16, const float* pos, void* out,
+                       int64_t B, int64_t T, int64_t D, int64_t vocab, void* stream);
+int clipa_embed_tokens_bwd(const int64_t* ids, const void* dx, float* dtable, float* dpos, int64_t B,
+                           int64_t T, int64_t D, int64_t vocab, void* stream);
+/* text.argmax(dim=-1) (model.py:254) */
+int clipa_argmax_tokens(const int64_t* ids, int32_t* out, int64_t B, int64_t T, void* stream);
+/* pooling [B,L,D] bf16 -> [B,D] f32 and its gradient (writes all of dx) */
+int clipa_pool_fwd(const void* x, const int32_t* idx, float* out, int64_t B, int64_t L, int64_t D, int mode,
+                   void* stream);
+int clipa_pool_bwd(const float* dout, const int32_t* idx, void* dx, int64_t B, int64_t L, int64_t D,
+                   int mode, void* stream);
+/* F.normalize(x, dim=-1) (model.py:240,263); y_bf16 optional second output */
+int clipa_l2norm_fwd(const float* x, float* y, void* y_bf16, float* inv_norm, int64_t rows, int64_t E,
+                     float eps, void* stream);
+int clipa_l2norm_bwd(const float* y, const float* inv_norm, const float* dy, float* dx, int64_t rows,
+                     int64_t E, void* stream);
+/* bias gradients: out[n] = sum_m dY[m,n] */
+int64_t clipa_colsum_workspace(int64_t M, int64_t N);
+int clipa_colsum(const void* dy, float* out, int64_t M, int64_t N, int64_t ld, void* workspace,
+                 int64_t workspace_bytes, void* stream);
+/* dtype / layout plumbing for weights */
+int clipa_cast_to_bf16(const void* in, int in_f32, void* out, int64_t n, void* stream);
+int clipa_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);
+int clipa_transpose_to_bf16(const void* in, int in_f32, void* out, int64_t R, int64_t C, int64_t ldi,
+                            int64_t ldo, void* stream);
+/* F.cross_entropy(logits, arange + label0) rows (loss.py:115-126,152-155): per-row loss, bf16 gradient
+ * gscale*(softmax - onehot) and per-row sum_j dlogits_j*logits_j (for d/d logit_scale). */
+int clipa_ce_rows(const float* logits, int64_t rows, int64_t N, int64_t ld, int64_t label0, float gscale,
+                  void* dlogits_bf16, int64_t ldd, float* loss_rows, float* dscale_rows, void* stream);
+int clipa_sum_scale(const float* in, float* out, int64_t n, float scale, int accumulate, void* stream);
+
+/* AdamW over one flat tensor (training/main.py:318-326 torch.optim.AdamW + train.py:285-286 clamp is
+ * done by the caller): p -= lr*(m_hat/(sqrt(v_hat)+eps) + wd*p). param/grad bf16 or f32; m, v f32. */
+int clipa_adamw(void* param, const void* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int param_f32,
+                int grad_f32, float lr, float beta1, float beta2, float eps, float weight_decay,
+                int64_t step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
