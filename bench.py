@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""bench.py - image-text pairs/sec of the full CLIP training step on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = what clipa_torch/training/train.py:187-291 does per iteration: uint8 batch (already resident in
+HBM) -> model forward -> global InfoNCE loss (local_loss + gather_with_grad, the reference GPU recipe) ->
+backward -> DDP gradient all-reduce -> AdamW -> logit_scale clamp.  Default workload = BASELINE.json's headline
+configuration at its per-GPU shape: ViT-L/16 @ 224, text-77, bf16 compute, local batch 4096 (weak scaling:
+global batch 4096*N, i.e. 32768 at N=8).  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
+
+
+def train_gflop_per_pair(cfg, S, ctx):
+    """F_tower = layers*L*(24 D^2 + 4 L D), patch GEMM, projections; training = 3x forward;
+    activation recompute NOT counted."""
+    v, t, E = cfg["vision_cfg"], cfg["text_cfg"], cfg["embed_dim"]
+    P, D = v["patch_size"], v["width"]
+    g = S // P
+    L = g * g + 1
+    fwd = v["layers"] * L * (24 * D * D + 4 * L * D) + g * g * 2 * 3 * P * P * D + 2 * D * E
+    Dt = t["width"]
+    fwd += t["layers"] * ctx * (24 * Dt * Dt + 4 * ctx * Dt) + 2 * Dt * E
+    return 3.0 * fwd / 1e9
+
+
+def cpu_baseline(cfg, S, ctx, sample_pairs, threads):
+    """The CPU port of the reference path (oracle/clip_oracle.py, fp32, torch CPU ops) on the host cores:
+    forward + loss + backward + AdamW on a bounded sample of the same workload."""
+    from oracle import clip_oracle as O
+    import clipa_amd
+    torch.set_num_threads(threads)
+    m = clipa_amd.CLIP(**cfg)                      # parameter container only (shapes / init); maths is the oracle's
+    sd = {k: v.detach().clone().float().requires_grad_(v.requires_grad) for k, v in m.named_parameters()}
+    ocfg = O.oracle_cfg(cfg)
+    opt = torch.optim.AdamW([p for p in sd.values() if p.requires_grad], lr=1e-4, betas=(0.9, 0.95), eps=1e-6,
+                            weight_decay=0.2)
+    img, txt = O.synthetic_batch(sample_pairs, S, ctx, cfg["text_cfg"]["vocab_size"], seed=1)
+
+    def step():
+        opt.zero_grad()
+        i, t, s = O.clip_forward(sd, ocfg, O.normalize_images(img), txt)
+        loss, _ = O.clip_loss(i, t, s)
+        loss.backward()
+        opt.step()
+        return float(loss)
+
+    step()                                          # warm-up
+    t0 = time.perf_counter()
+    n = 2
+    for _ in range(n):
+        step()
+    dt = (time.perf_counter() - t0) / n
+    return {"value": sample_pairs / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": f"{sample_pairs} pairs/step x {n} timed steps (+1 warm-up), fp32 fwd+loss+bwd+AdamW, "
+                      f"oracle/clip_oracle.py on torch CPU ops"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="ViT-L-16")
+    ap.add_argument("--image-size", type=int, default=224)
+    ap.add_argument("--ctx", type=int, default=77)
+    ap.add_argument("--batch", type=int, default=4096, help="local (per-GPU) batch")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "amp_bf16"],
+                    help="bf16 = reference 'bf16' mode (bf16 weights); amp_bf16 = fp32 master weights")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=4)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible - the MI355X engine has no CPU fallback", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+
+    import clipa_amd
+    from clipa_amd import ops
+    from clipa_amd.optim import AdamW
+    from oracle import clip_oracle as O
+
+    cfg = clipa_amd.get_model_config(args.model)
+    cfg["vision_cfg"]["image_size"] = args.image_size
+    cfg["text_cfg"]["context_length"] = args.ctx
+    torch.manual_seed(0)                                       # same init on every rank (main.py:231)
+    model = clipa_amd.create_model(args.model, precision="bf16" if args.precision == "bf16" else "amp_bf16",
+                                   device=dev, force_image_size=args.image_size, output_dict=True)
+    if args.ctx != model.positional_embedding.shape[0]:
+        model.positional_embedding = torch.nn.Parameter(model.positional_embedding[:args.ctx].clone())
+    model.set_grad_checkpointing(True)                         # every reference GPU script passes --grad-checkpointing
+    named = list(model.named_parameters())
+    exclude = lambda n, p: p.ndim < 2 or "bn" in n or "ln" in n or "bias" in n or "logit_scale" in n   # main.py:311-316
+    opt = AdamW([{"params": [p for n, p in named if exclude(n, p) and p.requires_grad], "weight_decay": 0.},
+                 {"params": [p for n, p in named if not exclude(n, p) and p.requires_grad], "weight_decay": 0.2}],
+                lr=5e-4, betas=(0.9, 0.95), eps=1e-6)
+    step_model = model
+    if world > 1:
+        step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], static_graph=True)
+    loss_fn = clipa_amd.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True, rank=rank, world_size=world)
+
+    B = args.batch
+    img_cpu, txt_cpu = O.synthetic_batch(min(B, 256), args.image_size, args.ctx, cfg["text_cfg"]["vocab_size"],
+                                         seed=1234 + rank)
+    reps = (B + img_cpu.shape[0] - 1) // img_cpu.shape[0]
+    images = img_cpu.to(dev).repeat(reps, 1, 1, 1)[:B].contiguous()
+    # de-duplicate the tiled synthetic images so no two pairs of the batch are identical
+    images += (torch.arange(B, device=dev, dtype=torch.int64) % 251).to(torch.uint8).view(B, 1, 1, 1)
+    texts = txt_cpu.to(dev).repeat(reps, 1)[:B].contiguous()
+    texts[:, 1] = 1 + (torch.arange(B, device=dev) % 40000)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = step_model(images, texts)
+        loss = loss_fn(**out, output_dict=True)["contrastive_loss"]
+        loss.backward()
+        opt.step()
+        with torch.no_grad():
+            model.logit_scale.clamp_(0, math.log(100))        # train.py:285-286
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ops.profile_start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = ops.profile_stop()
+    last_loss = float(loss)
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax)
+    if not math.isfinite(last_loss):
+        print(f"bench.py: non-finite loss {last_loss}", file=sys.stderr)
+        sys.exit(3)
+
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        pairs_s = B * world * args.steps / elapsed
+        gf = train_gflop_per_pair(cfg, args.image_size, args.ctx)
+        nt = prof.get("gemm_nt", {"launches": 0, "ms": 0.0, "work": 0.0})
+        achieved = nt["work"] / (nt["ms"] * 1e-3) / 1e12 if nt["ms"] > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("gemm_nt_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "image-text pairs/sec (whole job), full training step",
+            "value": round(pairs_s, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.model}@{args.image_size} + text-{args.ctx}, local batch {B}, "
+                                   f"global batch {B * world}, InfoNCE local_loss+gather_with_grad, AdamW, "
+                                   f"per-block recompute", "precision": args.precision, "parallelism": f"dp{world}",
+                       "global_batch": B * world, "train_gflop_per_pair": round(gf, 2)},
+            "model_flops_util": round(pairs_s / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4),
+            "loss": round(last_loss, 4),
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA 32x32x16)", "achieved": round(achieved, 1),
+                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                         "traffic": traffic, "launches": nt["launches"],
+                         "avg_launch_ms": round(nt["ms"] / max(nt["launches"], 1), 4)},
+            "kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 2),
+                            "tflops": round(v["work"] / max(v["ms"], 1e-9) / 1e9, 1)} for k, v in prof.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = os.cpu_count() or 1
+            line["cpu_baseline"] = cpu_baseline(cfg, args.image_size, args.ctx, args.cpu_sample, threads)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -21,6 +21,48 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ---- optional per-launch timing (bench.py roofline): HIP events on the launch stream ------------
+_PROF = None
+
+
+def profile_start():
+    global _PROF
+    _PROF = {}
+
+
+def profile_stop():
+    """-> {kernel: {"launches", "ms", "work"}}; work = algorithmic FLOPs (GEMM/attention) of the launches."""
+    global _PROF
+    prof, _PROF = _PROF, None
+    if not prof:
+        return {}
+    torch.cuda.synchronize()
+    out = {}
+    for name, recs in prof.items():
+        out[name] = {"launches": len(recs), "ms": sum(a.elapsed_time(b) for a, b, _ in recs),
+                     "work": float(sum(w for _, _, w in recs))}
+    return out
+
+
+class _Timed:
+    __slots__ = ("name", "work", "a")
+
+    def __init__(self, name, work):
+        self.name, self.work = name, work
+
+    def __enter__(self):
+        if _PROF is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if _PROF is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            _PROF.setdefault(self.name, []).append((self.a, b, self.work))
+        return False
+
+
 def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -64,8 +106,9 @@ def gemm_nt(a, b, bias=None, *, epi=EPI_NONE, act=ACT_GELU_ERF, aux=None, alpha=
     if aux is not None:
         _chk(aux, bf16, "aux", 2)
         aux, ldaux = _rowmajor(aux)
-    lib.call("clipa_gemm_nt", _p(a), _p(b), _p(out), _p(pre), _p(bias), _p(aux), M, N, K, lda, ldb, ldc, ldaux,
-             float(alpha), epi, act, 1 if out_f32 else 0, _stream())
+    with _Timed("gemm_nt", 2.0 * M * N * K):
+        lib.call("clipa_gemm_nt", _p(a), _p(b), _p(out), _p(pre), _p(bias), _p(aux), M, N, K, lda, ldb, ldc, ldaux,
+                 float(alpha), epi, act, 1 if out_f32 else 0, _stream())
     return (out, pre) if want_pre else out
 
 
@@ -83,8 +126,9 @@ def gemm_tn(p, q, out_dtype=f32):
     wsb = lib.query("clipa_gemm_tn_workspace", M, R, C, ctypes.byref(ns))
     ws = torch.empty(max(wsb, 4) // 4, device=p.device, dtype=f32)
     out = torch.empty((R, C), device=p.device, dtype=out_dtype)
-    lib.call("clipa_gemm_tn", _p(p), _p(q), _p(out), M, R, C, ldp, ldq, 1 if out_dtype == bf16 else 0, _p(ws),
-             wsb, _stream())
+    with _Timed("gemm_tn", 2.0 * M * R * C):
+        lib.call("clipa_gemm_tn", _p(p), _p(q), _p(out), M, R, C, ldp, ldq, 1 if out_dtype == bf16 else 0, _p(ws),
+                 wsb, _stream())
     return out
 
 
@@ -129,8 +173,9 @@ def attention_fwd(qkv, B, L, H, causal):
     out = torch.empty((B * L, D), device=qkv.device, dtype=bf16)
     base = qkv.data_ptr()
     ld = qkv.stride(0)
-    lib.call("clipa_attention_fwd", ctypes.c_void_p(base), ctypes.c_void_p(base + 2 * D), ctypes.c_void_p(base + 4 * D),
-             _p(out), B, H, L, dh, ld, D, 1.0 / math.sqrt(dh), int(causal), _stream())
+    with _Timed("attention_fwd", 4.0 * B * H * L * L * dh * (0.5 if causal else 1.0)):
+        lib.call("clipa_attention_fwd", ctypes.c_void_p(base), ctypes.c_void_p(base + 2 * D),
+                 ctypes.c_void_p(base + 4 * D), _p(out), B, H, L, dh, ld, D, 1.0 / math.sqrt(dh), int(causal), _stream())
     return out
 
 
@@ -143,9 +188,11 @@ def attention_bwd(qkv, out, dout, B, L, H, causal):
     dh = D // H
     dqkv = torch.empty_like(qkv)
     base, dbase = qkv.data_ptr(), dqkv.data_ptr()
-    lib.call("clipa_attention_bwd", ctypes.c_void_p(base), ctypes.c_void_p(base + 2 * D), ctypes.c_void_p(base + 4 * D),
-             _p(out), _p(dout), ctypes.c_void_p(dbase), ctypes.c_void_p(dbase + 2 * D), ctypes.c_void_p(dbase + 4 * D),
-             B, H, L, dh, qkv.stride(0), D, dqkv.stride(0), 1.0 / math.sqrt(dh), int(causal), _stream())
+    with _Timed("attention_bwd", 10.0 * B * H * L * L * dh * (0.5 if causal else 1.0)):
+        lib.call("clipa_attention_bwd", ctypes.c_void_p(base), ctypes.c_void_p(base + 2 * D),
+                 ctypes.c_void_p(base + 4 * D), _p(out), _p(dout), ctypes.c_void_p(dbase), ctypes.c_void_p(dbase + 2 * D),
+                 ctypes.c_void_p(dbase + 4 * D), B, H, L, dh, qkv.stride(0), D, dqkv.stride(0), 1.0 / math.sqrt(dh),
+                 int(causal), _stream())
     return dqkv
 
 

@@ -1,0 +1,189 @@
+"""TEST INFRASTRUCTURE: torch-CPU stand-ins for clipa_amd.ops with the same signatures and the same bf16
+storage points, so the host-side orchestration (autograd glue in clipa_amd.engine / model / loss: shapes,
+operand forms, gradient wiring, recompute) can be exercised without a GPU.  Never imported by the product."""
+import math
+
+import torch
+
+from oracle import clip_oracle as O
+
+EPI_NONE, EPI_ACT, EPI_ADD, EPI_DACT = 0, 1, 2, 3
+ACT_GELU_ERF, ACT_GELU_TANH, ACT_QUICK_GELU = 0, 1, 2
+DT_U8, DT_BF16, DT_F32 = 0, 1, 2
+POOL_FIRST, POOL_LAST, POOL_INDEX, POOL_MEAN_ALL, POOL_MEAN_PATCH = 0, 1, 2, 3, 4
+bf16, f32 = torch.bfloat16, torch.float32
+_ACT = {0: "gelu_erf", 1: "gelu_tanh", 2: "quick_gelu"}
+
+
+def _act(x, a):
+    return O.activation(x, _ACT[a])
+
+
+def _dact(x, a):
+    x = x.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        _act(x, a).sum().backward()
+    return x.grad
+
+
+def gemm_nt(a, b, bias=None, *, epi=EPI_NONE, act=0, aux=None, alpha=1.0, out_f32=False, want_pre=False, out=None):
+    v = (a.float() @ b.float().T) * alpha
+    if bias is not None:
+        v = v + bias.float()
+    if out_f32:
+        return v
+    v = v.to(bf16)
+    pre = v
+    if epi == EPI_ACT:
+        v = _act(v.float(), act).to(bf16)
+    elif epi == EPI_ADD:
+        v = (v.float() + aux.float()).to(bf16)
+    elif epi == EPI_DACT:
+        v = (v.float() * _dact(aux.float(), act)).to(bf16)
+    return (v, pre) if want_pre else v
+
+
+def gemm_tn(p, q, out_dtype=f32):
+    return (p.float().T @ q.float()).to(out_dtype)
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=None):
+    return O.layer_norm(x.float(), gamma, beta, eps).to(out_dtype or x.dtype)
+
+
+def layernorm_bwd(x, gamma, dy, dres=None, eps=1e-5):
+    xr = x.float().detach().requires_grad_(True)
+    g = gamma.detach().clone().requires_grad_(True)
+    b = torch.zeros_like(g, requires_grad=True)
+    with torch.enable_grad():
+        O.layer_norm(xr, g, b, eps).backward(dy.float())
+    dx = xr.grad + (dres.float() if dres is not None else 0)
+    return dx.to(x.dtype), g.grad, b.grad
+
+
+def attention_fwd(qkv, B, L, H, causal):
+    D = qkv.shape[1] // 3
+    return O.attention(qkv.float().reshape(B, L, 3 * D), H, causal).reshape(B * L, D).to(bf16)
+
+
+def attention_bwd(qkv, out, dout, B, L, H, causal):
+    D = qkv.shape[1] // 3
+    x = qkv.float().reshape(B, L, 3 * D).detach().requires_grad_(True)
+    with torch.enable_grad():
+        O.attention(x, H, causal).backward(dout.float().reshape(B, L, D))
+    return x.grad.reshape(B * L, 3 * D).to(bf16)
+
+
+def patchify(img, P, Kp, mean=None, std=None):
+    B, _, S, _ = img.shape
+    g = S // P
+    x = O.normalize_images(img, mean, std) if mean is not None else img.float()
+    K = 3 * P * P
+    pt = x[:, :, :g * P, :g * P].reshape(B, 3, g, P, g, P).permute(0, 2, 4, 3, 5, 1).reshape(B * g * g, K)
+    return torch.nn.functional.pad(pt, (0, Kp - K)).to(bf16)
+
+
+def assemble_tokens(patch, cls, pos, B, L):
+    D = patch.shape[1]
+    x = torch.cat([cls.to(bf16).float().expand(B, 1, D), patch.float().reshape(B, L - 1, D)], 1) + pos.to(bf16).float()
+    return x.reshape(B * L, D).to(bf16)
+
+
+def assemble_tokens_bwd(dtok, B, L, need_pos=True):
+    D = dtok.shape[1]
+    d = dtok.float().reshape(B, L, D)
+    return d[:, 1:].reshape(-1, D).to(bf16), d[:, 0].sum(0), (d.sum(0) if need_pos else None)
+
+
+def embed_tokens(ids, table, pos):
+    B, T = ids.shape
+    return (table.to(bf16).float()[ids] + pos.to(bf16).float()).reshape(B * T, -1).to(bf16)
+
+
+def embed_tokens_bwd(ids, dx, vocab, need_table=True, need_pos=True):
+    B, T = ids.shape
+    D = dx.shape[1]
+    dt = torch.zeros(vocab, D).index_add_(0, ids.reshape(-1), dx.float()) if need_table else None
+    dp = dx.float().reshape(B, T, D).sum(0) if need_pos else None
+    return dt, dp
+
+
+def argmax_tokens(ids):
+    return ids.argmax(-1).to(torch.int32)
+
+
+def _pool(x3, mode, idx):
+    B = x3.shape[0]
+    if mode == POOL_FIRST:
+        return x3[:, 0]
+    if mode == POOL_LAST:
+        return x3[:, -1]
+    if mode == POOL_INDEX:
+        return x3[torch.arange(B), idx.long()]
+    if mode == POOL_MEAN_ALL:
+        return x3.mean(1)
+    return x3[:, 1:].mean(1)
+
+
+def pool_fwd(x, B, L, mode, idx=None):
+    return _pool(x.float().reshape(B, L, -1), mode, idx)
+
+
+def pool_bwd(dout, B, L, mode, idx=None):
+    x = torch.zeros(B, L, dout.shape[-1], requires_grad=True)
+    with torch.enable_grad():
+        _pool(x, mode, idx).backward(dout.float())
+    return x.grad.reshape(B * L, -1).to(bf16)
+
+
+def l2norm_fwd(x, eps=1e-12, want_bf16=False):
+    n = x.norm(dim=-1).clamp_min(eps)
+    y = x / n[:, None]
+    return y, (y.to(bf16) if want_bf16 else None), 1.0 / n
+
+
+def l2norm_bwd(y, inv, dy):
+    return inv[:, None] * (dy - y * (y * dy).sum(-1, keepdim=True))
+
+
+def colsum(dy):
+    return dy.float().sum(0)
+
+
+def to_bf16(t):
+    return t.to(bf16)
+
+
+def to_f32(t):
+    return t.float()
+
+
+def transpose_bf16(t):
+    return t.to(bf16).T.contiguous()
+
+
+def ce_rows(logits, label0, gscale, want_grad=True):
+    R, N = logits.shape
+    labels = torch.arange(R) + label0
+    loss_rows = torch.logsumexp(logits, dim=1) - logits[torch.arange(R), labels]
+    p = torch.softmax(logits, dim=1)
+    p[torch.arange(R), labels] -= 1.0
+    g = p * gscale
+    return loss_rows, (g.to(bf16) if want_grad else None), (g * logits).sum(1)
+
+
+def sum_scale(x, scale, out=None, accumulate=False):
+    v = (x.sum() * scale).reshape(())
+    if out is None:
+        return v
+    out.copy_(out + v if accumulate else v)
+    return out
+
+
+def adamw_(param, grad, exp_avg, exp_avg_sq, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    g = grad.float() * grad_scale
+    p = param.float() * (1 - lr * weight_decay)
+    exp_avg.mul_(beta1).add_(g, alpha=1 - beta1)
+    exp_avg_sq.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    denom = exp_avg_sq.sqrt() / math.sqrt(1 - beta2 ** step) + eps
+    param.copy_((p - lr / (1 - beta1 ** step) * exp_avg / denom).to(param.dtype))

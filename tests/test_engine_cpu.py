@@ -1,0 +1,113 @@
+"""CPU test of the host-side orchestration: the real clipa_amd.engine / model / loss / optim code runs with
+its `ops` module swapped (in this test only) for the torch-CPU stand-ins of tests/cpu_ops.py, and the result
+- features, loss, EVERY parameter gradient - is compared with the golden vectors of the real reference.
+What this pins without a GPU: operand forms (W vs W^T), gradient wiring of all 12 per-block parameters,
+stem / head / pooling variants, recompute-vs-stored equivalence, the optimizer's version bump."""
+import math
+
+import pytest
+
+from .conftest import load_golden
+import torch
+
+import clipa_amd
+from clipa_amd import engine, loss as loss_mod, model as model_mod, optim as optim_mod
+from oracle import clip_oracle as O
+
+from . import cpu_ops
+
+
+@pytest.fixture(autouse=True)
+def _swap_ops(monkeypatch):
+    for mod in (engine, loss_mod, model_mod, optim_mod):
+        monkeypatch.setattr(mod, "ops", cpu_ops)
+
+
+def _run(g, recompute=True, precision="fp32"):
+    m = clipa_amd.CLIP(**g.cfg, output_dict=True)
+    m.load_state_dict(g.sd, strict=True)
+    if precision == "bf16":
+        clipa_amd.convert_weights_to_lp(m, torch.bfloat16)
+    m.set_grad_checkpointing(recompute)
+    out = m(g.images_u8, g.texts)
+    loss = clipa_amd.ClipLoss()(**out, output_dict=True)["contrastive_loss"]
+    loss.backward()
+    return m, out, loss
+
+
+def test_engine_orchestration_matches_reference_golden(golden):
+    g = golden
+    m, out, loss = _run(g)
+    assert (out["image_features"] - g.t("image_features")).abs().max() < 2e-2
+    assert (out["text_features"] - g.t("text_features")).abs().max() < 2e-2
+    assert abs(float(loss) - float(g.t("loss"))) < 2e-2 * float(g.t("loss"))
+    sd = {k: v.clone().requires_grad_(k not in g.frozen) for k, v in g.sd.items()}
+    i, t, s = O.clip_forward(sd, g.ocfg, O.normalize_images(g.images_u8), g.texts)
+    O.clip_loss(i, t, s)[0].backward()
+    names = [str(n) for n in g.z["grad_names"]]
+    got = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    assert sorted(got) == names
+    for n in names:
+        a, b = got[n].double().reshape(-1), sd[n].grad.double().reshape(-1)
+        assert got[n].shape == sd[n].shape and got[n].dtype == dict(m.named_parameters())[n].dtype, n
+        if float(b.norm()) < 1e-7:
+            continue
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+        assert cos > 0.99, (n, cos)
+        assert abs(float(a.norm() / b.norm()) - 1) < 0.05, n
+
+
+def test_recompute_equals_stored(golden):
+    ma, _, la = _run(golden, recompute=True)
+    mb, _, lb = _run(golden, recompute=False)
+    assert float(la) == float(lb)
+    for (k, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
+        if p.grad is not None:
+            assert torch.equal(p.grad, q.grad), k
+
+
+def test_bf16_precision_mode_and_frozen_tower(golden):
+    m, _, loss = _run(golden, precision="bf16")
+    for k, p in m.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and p.grad.dtype == p.dtype, k
+    m2 = clipa_amd.CLIP(**golden.cfg, output_dict=True)
+    m2.load_state_dict(golden.sd)
+    m2.lock_image_tower(unlocked_groups=1)
+    out = m2(golden.images_u8, golden.texts)
+    clipa_amd.ClipLoss()(**out).backward()
+    assert m2.visual.proj.grad is not None and m2.visual.conv1.weight.grad is None
+    assert m2.visual.transformer.resblocks[0].mlp.c_fc.weight.grad is None
+
+
+def test_optimizer_step_refreshes_weight_cache_and_reduces_loss():
+    g = load_golden("cls_erf")
+    m = clipa_amd.CLIP(**g.cfg, output_dict=True)
+    m.load_state_dict(g.sd)
+    opt = clipa_amd.optim.AdamW(m.parameters(), lr=2e-3, betas=(0.9, 0.95), eps=1e-6, weight_decay=0.0)
+    losses = []
+    for _ in range(5):
+        opt.zero_grad()
+        out = m(g.images_u8, g.texts)
+        loss = clipa_amd.ClipLoss()(**out)
+        loss.backward()
+        opt.step()
+        with torch.no_grad():
+            m.logit_scale.clamp_(0, math.log(100))
+        losses.append(float(loss))
+    assert losses[-1] < losses[0] - 0.2, losses      # stale cached weights would keep the loss flat
+
+
+def test_encode_entry_points(golden):
+    m = clipa_amd.CLIP(**golden.cfg)
+    m.load_state_dict(golden.sd)
+    with torch.no_grad():
+        i = m.encode_image(golden.images_u8, normalize=True)
+        t = m.encode_text(golden.texts, normalize=True)
+        raw = m.encode_image(golden.images_u8)
+        tup = m(golden.images_u8, golden.texts)
+    assert isinstance(tup, tuple) and len(tup) == 3          # output_dict=False contract (model.py:274)
+    assert torch.allclose(raw / raw.norm(dim=-1, keepdim=True), i, atol=1e-6)
+    assert (i - golden.t("image_features")).abs().max() < 2e-2 and (t - golden.t("text_features")).abs().max() < 2e-2
+    with pytest.raises(RuntimeError):
+        m.encode_text(golden.texts[:, :-1])

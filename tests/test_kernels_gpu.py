@@ -1,0 +1,286 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (clipa_amd.ops -> libclipa_hip.so) against the
+CPU oracle maths (oracle/clip_oracle.py) / plain fp32 torch on the same seeded inputs.
+
+Tolerances (stated per check): GEMM-type outputs are compared against an fp64-accumulated product of the
+SAME bf16 operands, so the only differences are fp32 accumulation order and the final bf16 rounding
+(<= 2^-8 relative); HBM-bound fp32 kernels are held to ~1e-5.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import clip_oracle as O
+
+pytestmark = pytest.mark.gpu
+bf16, f32 = torch.bfloat16, torch.float32
+DEV = "cuda"
+
+
+def ops():
+    from clipa_amd import ops as _ops
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=bf16):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def check(name, got, ref, rtol, atol):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{name}: non-finite output"
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    if bad.any():
+        i = int(torch.argmax((err - tol).reshape(-1)))
+        idx = np.unravel_index(i, tuple(got.shape)) if got.dim() else ()
+        raise AssertionError(f"{name}: {int(bad.sum())}/{got.numel()} outside tol; worst at {idx}: got "
+                             f"{got.reshape(-1)[i].item():.6g} ref {ref.reshape(-1)[i].item():.6g} "
+                             f"(max abs err {err.max().item():.3g})")
+
+
+def ref_act(x, act):
+    return O.activation(x, {0: "gelu_erf", 1: "gelu_tanh", 2: "quick_gelu"}[act])
+
+
+# -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 264, 136), (1000, 768, 1024), (77, 2304, 768), (512, 512, 3072)])
+def test_gemm_nt_plain_bias_f32out(M, N, K):
+    a, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)     # asymmetric operands
+    bias = rnd(N, seed=3, dtype=f32)
+    ref = a.double() @ b.double().T * 0.5 + bias.double()
+    out = ops().gemm_nt(a.to(DEV), b.to(DEV), bias.to(DEV), alpha=0.5)
+    check("bf16 out", out, ref, 2 ** -7, 2e-3)
+    out32 = ops().gemm_nt(a.to(DEV), b.to(DEV), bias.to(DEV), alpha=0.5, out_f32=True)
+    check("f32 out", out32, ref, 1e-4, 2e-4 * math.sqrt(K))
+
+
+def test_gemm_nt_strided_operands():
+    M, N, K = 320, 264, 128
+    big_a, big_b = rnd(M, 3 * K, seed=4).to(DEV), rnd(N, 2 * K, seed=5, scale=0.05).to(DEV)
+    a, b = big_a[:, K:2 * K], big_b[:, K:]
+    out = ops().gemm_nt(a, b, out_f32=True)
+    check("strided", out, a.double().cpu() @ b.double().cpu().T, 1e-4, 3e-3)
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm_nt_epilogues(act):
+    M, N, K = 520, 384, 256
+    a, b = rnd(M, K, seed=6), rnd(N, K, seed=7, scale=0.08)
+    bias, aux = rnd(N, seed=8, dtype=f32), rnd(M, N, seed=9)
+    v = (a.double() @ b.double().T + bias.double()).to(bf16).double()       # engine rounds the GEMM output to bf16
+    A, B, BIAS, AUX = a.to(DEV), b.to(DEV), bias.to(DEV), aux.to(DEV)
+    out, pre = ops().gemm_nt(A, B, BIAS, epi=ops().EPI_ACT, act=act, want_pre=True)
+    check("pre-activation", pre, v, 2 ** -7, 2e-3)
+    check("act", out, ref_act(pre.double().cpu(), act), 2 ** -7, 2e-3)
+    out = ops().gemm_nt(A, B, BIAS, epi=ops().EPI_ADD, aux=AUX)
+    check("residual add", out, v + aux.double(), 2 ** -7, 8e-3)
+    x = aux.double().clone().requires_grad_(True)
+    ref_act(x, act).sum().backward()
+    out = ops().gemm_nt(A, B, BIAS, epi=ops().EPI_DACT, act=act, aux=AUX)
+    check("act backward", out, v * x.grad, 2 ** -6, 6e-3)
+
+
+@pytest.mark.parametrize("M,R,C", [(64, 256, 256), (1000, 264, 136), (4100, 1024, 512), (130, 8, 2304), (8, 16, 16)])
+def test_gemm_tn(M, R, C):
+    p, q = rnd(M, R, seed=10), rnd(M, C, seed=11, scale=0.1)
+    ref = p.double().T @ q.double()
+    out = ops().gemm_tn(p.to(DEV), q.to(DEV), f32)
+    check("f32", out, ref, 1e-4, 3e-4 * math.sqrt(M))
+    out = ops().gemm_tn(p.to(DEV), q.to(DEV), bf16)
+    check("bf16", out, ref, 2 ** -7, 3e-4 * math.sqrt(M))
+
+
+def test_gemm_tn_strided_and_many_slices():
+    M, R, C = 70000, 136, 72
+    big = rnd(M, R + C, seed=12, scale=0.2).to(DEV)
+    p, q = big[:, :R], big[:, R:]
+    out = ops().gemm_tn(p, q, f32)
+    check("slices", out, p.double().cpu().T @ q.double().cpu(), 2e-4, 2e-2)
+
+
+# -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D", [384, 768, 1024, 1280])
+@pytest.mark.parametrize("xdt,ydt", [(bf16, bf16), (f32, bf16), (f32, f32)])
+def test_layernorm(D, xdt, ydt):
+    rows = 777
+    x = (rnd(rows, D, seed=20, dtype=f32) * 1.5 + 0.3).to(xdt)
+    w, b = 1 + 0.1 * rnd(D, seed=21, dtype=f32), 0.1 * rnd(D, seed=22, dtype=f32)
+    dy, dres = rnd(rows, D, seed=23, dtype=ydt), rnd(rows, D, seed=24, dtype=xdt)
+    xr = x.double().requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = O.layer_norm(xr, wr, br)
+    yr.backward(dy.double())
+    y = ops().layernorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5, out_dtype=ydt)
+    tol = 2 ** -7 if ydt == bf16 else 2e-5
+    check("fwd", y, yr, tol, tol)
+    dx, dw, db = ops().layernorm_bwd(x.to(DEV), w.to(DEV), dy.to(DEV), dres.to(DEV), 1e-5)
+    tolx = 2 ** -7 if xdt == bf16 else 3e-5
+    check("dx", dx, xr.grad + dres.double(), tolx, tolx * 4)
+    check("dgamma", dw, wr.grad, 1e-4, 2e-3)
+    check("dbeta", db, br.grad, 1e-4, 2e-3)
+    dx2, _, _ = ops().layernorm_bwd(x.to(DEV), w.to(DEV), dy.to(DEV), None, 1e-5)
+    check("dx no-res", dx2, xr.grad, tolx, tolx * 4)
+
+
+# -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,L,causal", [(2, 3, 26, False), (3, 2, 50, False), (2, 2, 77, True), (2, 4, 197, False),
+                                          (1, 2, 257, False), (2, 1, 8, True), (2, 2, 32, True), (1, 2, 288, True)])
+def test_attention(B, H, L, causal):
+    D = 64 * H
+    qkv = rnd(B * L, 3 * D, seed=30 + L, scale=1.2)
+    dout = rnd(B * L, D, seed=31 + L)
+    x = qkv.double().reshape(B, L, 3 * D).requires_grad_(True)
+    o = O.attention(x, H, causal)
+    o.backward(dout.double().reshape(B, L, D))
+    got = ops().attention_fwd(qkv.to(DEV), B, L, H, causal)
+    check("fwd", got.reshape(B, L, D), o, 2 ** -6, 8e-3)
+    dq = ops().attention_bwd(qkv.to(DEV), got, dout.to(DEV), B, L, H, causal)
+    check("dqkv", dq.reshape(B, L, 3 * D), x.grad, 2 ** -5, 2e-2)
+
+
+def test_attention_reads_packed_projection_in_place():
+    """q/k/v are column blocks of a wider buffer (row stride != 3D) - no head-major copy is made."""
+    B, H, L = 2, 2, 50
+    D = 64 * H
+    wide = rnd(B * L, 3 * D + 64, seed=40).to(DEV)
+    qkv = wide[:, :3 * D]
+    ref = ops().attention_fwd(qkv.contiguous(), B, L, H, False)
+    got = ops().attention_fwd(qkv, B, L, H, False)
+    assert torch.equal(ref, got)
+
+
+def test_attention_large_logits_stable():
+    B, H, L = 1, 1, 64
+    qkv = rnd(B * L, 192, seed=41, scale=6.0)
+    x = qkv.double().reshape(B, L, 192)
+    got = ops().attention_fwd(qkv.to(DEV), B, L, H, True)
+    check("spiky", got.reshape(B, L, 64), O.attention(x, H, True), 2 ** -5, 3e-2)
+
+
+# -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("S,P", [(48, 16), (40, 16), (42, 14)])
+@pytest.mark.parametrize("kind", ["u8", "f32", "bf16", "u8_nhwc"])
+def test_patchify(S, P, kind):
+    B = 3
+    g = S // P
+    img_u8, _ = O.synthetic_batch(B, S, 8, 100, seed=50)
+    K = 3 * P * P
+    Kp = (K + 7) // 8 * 8
+    if kind.startswith("u8"):
+        x = img_u8
+        xin = x.to(DEV)
+        if kind == "u8_nhwc":
+            xin = xin.contiguous(memory_format=torch.channels_last)
+        ref_img = O.normalize_images(x)
+        got = ops().patchify(xin, P, Kp, O.OPENAI_DATASET_MEAN, O.OPENAI_DATASET_STD)
+    else:
+        dt = f32 if kind == "f32" else bf16
+        ref_img = O.normalize_images(img_u8).to(dt)
+        got = ops().patchify(ref_img.to(DEV), P, Kp)
+        ref_img = ref_img.float()
+    ref = ref_img[:, :, :g * P, :g * P].reshape(B, 3, g, P, g, P).permute(0, 2, 4, 3, 5, 1).reshape(B * g * g, K)
+    check("patches", got[:, :K], ref, 2 ** -8, 1e-6)
+    assert (got[:, K:] == 0).all()
+
+
+def test_assemble_embed_pool_l2norm_colsum_cast():
+    o = ops()
+    B, L, D = 5, 10, 128
+    patch = rnd((B * (L - 1)), D, seed=60)
+    cls, pos = rnd(D, seed=61, dtype=f32), rnd(L, D, seed=62, dtype=f32)
+    tok = o.assemble_tokens(patch.to(DEV), cls.to(DEV), pos.to(DEV), B, L)
+    ref = torch.cat([cls.to(bf16).float().expand(B, 1, D), patch.float().reshape(B, L - 1, D)], 1) + pos.to(bf16).float()
+    check("assemble", tok.reshape(B, L, D), ref, 2 ** -8, 1e-6)
+    dtok = rnd(B * L, D, seed=63)
+    dpatch, dcls, dpos = o.assemble_tokens_bwd(dtok.to(DEV), B, L)
+    d3 = dtok.float().reshape(B, L, D)
+    check("dpatch", dpatch, d3[:, 1:].reshape(-1, D), 0, 0)
+    check("dcls", dcls, d3[:, 0].sum(0), 1e-5, 1e-5)
+    check("dpos", dpos, d3.sum(0), 1e-5, 1e-5)
+
+    V, T = 300, 12
+    _, ids = O.synthetic_batch(B, 16, T, V, seed=64)
+    table = rnd(V, D, seed=65, dtype=f32, scale=0.02)
+    tpos = rnd(T, D, seed=66, dtype=f32, scale=0.01)
+    emb = o.embed_tokens(ids.to(DEV), table.to(DEV), tpos.to(DEV))
+    ref = table.to(bf16).float()[ids] + tpos.to(bf16).float()
+    check("embed", emb.reshape(B, T, D), ref, 2 ** -8, 1e-7)
+    dx = rnd(B * T, D, seed=67)
+    dx[T - 3:T] = 0                      # all-zero rows are skipped, result unchanged
+    dtable, dtpos = o.embed_tokens_bwd(ids.to(DEV), dx.to(DEV), V)
+    ref_t = torch.zeros(V, D, dtype=torch.float64).index_add_(0, ids.reshape(-1), dx.double())
+    check("dtable", dtable, ref_t, 1e-5, 1e-5)
+    check("dtpos", dtpos, dx.double().reshape(B, T, D).sum(0), 1e-5, 1e-5)
+    assert torch.equal(o.argmax_tokens(ids.to(DEV)).cpu().long(), ids.argmax(-1))
+
+    x = rnd(B * L, D, seed=68)
+    idx = torch.tensor([3, 0, 9, 5, 1], dtype=torch.int32)
+    x3 = x.double().reshape(B, L, D)
+    refs = {o.POOL_FIRST: x3[:, 0], o.POOL_LAST: x3[:, -1], o.POOL_INDEX: x3[torch.arange(B), idx.long()],
+            o.POOL_MEAN_ALL: x3.mean(1), o.POOL_MEAN_PATCH: x3[:, 1:].mean(1)}
+    dout = rnd(B, D, seed=69, dtype=f32)
+    for mode, ref in refs.items():
+        ii = idx.to(DEV) if mode == o.POOL_INDEX else None
+        check(f"pool{mode}", o.pool_fwd(x.to(DEV), B, L, mode, ii), ref, 1e-6, 1e-6)
+        xr = x3.clone().requires_grad_(True)
+        pooled = {o.POOL_FIRST: xr[:, 0], o.POOL_LAST: xr[:, -1], o.POOL_INDEX: xr[torch.arange(B), idx.long()],
+                  o.POOL_MEAN_ALL: xr.mean(1), o.POOL_MEAN_PATCH: xr[:, 1:].mean(1)}[mode]
+        pooled.backward(dout.double())
+        check(f"pool_bwd{mode}", o.pool_bwd(dout.to(DEV), B, L, mode, ii).reshape(B, L, D), xr.grad, 2 ** -8, 1e-7)
+
+    feat = rnd(37, 96, seed=70, dtype=f32)
+    fr = feat.double().requires_grad_(True)
+    yr = O.l2_normalize(fr)
+    dy = rnd(37, 96, seed=71, dtype=f32)
+    yr.backward(dy.double())
+    y, ybf, inv = o.l2norm_fwd(feat.to(DEV), want_bf16=True)
+    check("l2norm", y, yr, 1e-6, 1e-6)
+    check("l2norm bf16", ybf, yr, 2 ** -8, 1e-6)
+    check("l2norm bwd", o.l2norm_bwd(y, inv, dy.to(DEV)), fr.grad, 1e-5, 1e-5)
+
+    m = rnd(5000, 1032, seed=72)
+    check("colsum", o.colsum(m.to(DEV)), m.double().sum(0), 1e-5, 1e-3)
+    w = rnd(200, 136, seed=73, dtype=f32)
+    check("transpose", o.transpose_bf16(w.to(DEV)), w.to(bf16).T, 0, 0)
+    check("to_bf16", o.to_bf16(w.to(DEV)), w.to(bf16), 0, 0)
+    check("to_f32", o.to_f32(w.to(bf16).to(DEV)), w.to(bf16).float(), 0, 0)
+
+
+@pytest.mark.parametrize("R,N,label0", [(8, 8, 0), (16, 64, 48), (300, 4096, 1000)])
+def test_cross_entropy_rows(R, N, label0):
+    logits = rnd(R, N, seed=80, dtype=f32, scale=4.0)
+    lr = logits.double().requires_grad_(True)
+    labels = torch.arange(R) + label0
+    per = torch.nn.functional.cross_entropy(lr, labels, reduction="none")
+    gs = 0.5 / R
+    (per.sum() * gs).backward()
+    loss_rows, dl, ds = ops().ce_rows(logits.to(DEV), label0, gs)
+    check("loss rows", loss_rows, per, 1e-5, 1e-5)
+    check("dlogits", dl, lr.grad, 2 ** -7, 1e-7)
+    check("dscale rows", ds, (lr.grad * logits.double()).sum(1), 1e-3, 1e-4)
+    check("sum", ops().sum_scale(loss_rows, gs), per.sum() * gs, 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("pdt,gdt", [(f32, f32), (bf16, bf16), (f32, bf16)])
+def test_adamw_matches_torch(pdt, gdt):
+    n = 10007
+    p0, g = rnd(n, seed=90, dtype=f32), rnd(n, seed=91, dtype=f32, scale=0.1)
+    ref = torch.nn.Parameter(p0.to(pdt).double())
+    opt = torch.optim.AdamW([ref], lr=1e-3, betas=(0.9, 0.95), eps=1e-6, weight_decay=0.2)
+    p = p0.to(pdt).to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in (1, 2, 3):
+        gstep = (g * step).to(gdt)
+        ref.grad = gstep.double()
+        opt.step()
+        if pdt == bf16:
+            ref.data = ref.data.to(bf16).double()
+        ops().adamw_(p, gstep.to(DEV), m, v, lr=1e-3, beta1=0.9, beta2=0.95, eps=1e-6,
+                     weight_decay=0.2, step=step)
+    check("adamw", p, ref.data, 2 ** -7 if pdt == bf16 else 1e-5, 1e-6)

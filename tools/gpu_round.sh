@@ -1,0 +1,37 @@
+#!/bin/bash
+# One batched GPU-box session: parity tests, smoke, micro-benchmarks, a short bench.  Everything lands in
+# gpurun_out/ (merged back by gpurun).  Usage: gpurun --timeout 1800 -- 'bash tools/gpu_round.sh [stage...]'
+set -u
+mkdir -p gpurun_out
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+STAGES="${*:-tests smoke micro bench_small}"
+rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu.txt
+nproc >> gpurun_out/gpu.txt
+for s in $STAGES; do
+  case $s in
+    tests)
+      timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+      echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log ;;
+    smoke)
+      timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "rc=$?" >> gpurun_out/smoke.log ;;
+    micro)
+      timeout 900 python tools/microbench.py --quick > gpurun_out/microbench.jsonl 2> gpurun_out/microbench.err ;;
+    microfull)
+      timeout 1200 python tools/microbench.py > gpurun_out/microbench_full.jsonl 2> gpurun_out/microbench_full.err ;;
+    bench_small)
+      timeout 600 python bench.py --batch 512 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_small.log 2>&1
+      echo "rc=$?" >> gpurun_out/bench_small.log ;;
+    bench)
+      timeout 1500 python bench.py > gpurun_out/bench.log 2>&1; echo "rc=$?" >> gpurun_out/bench.log ;;
+    prof)
+      mkdir -p gpurun_out/prof
+      (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o r01 -- \
+         python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_bench.log" 2>&1)
+      echo "rc=$?" >> gpurun_out/prof_bench.log ;;
+  esac
+done
+echo "=== pytest tail"; tail -n 40 gpurun_out/pytest_gpu.log 2>/dev/null
+echo "=== smoke"; tail -n 5 gpurun_out/smoke.log 2>/dev/null
+echo "=== micro"; tail -n 60 gpurun_out/microbench.jsonl 2>/dev/null; tail -n 5 gpurun_out/microbench.err 2>/dev/null
+echo "=== bench"; tail -n 6 gpurun_out/bench_small.log 2>/dev/null; tail -n 6 gpurun_out/bench.log 2>/dev/null
