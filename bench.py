@@ -39,6 +39,19 @@ def train_gflop_per_pair(cfg, S, ctx):
     return 3.0 * fwd / 1e9
 
 
+def usable_cores(cap=64):
+    """Host cores this process may really use: affinity mask and cgroup CPU quota, capped (an OpenMP team far
+    larger than the quota spin-waits and is slower than a small one)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
 def cpu_baseline(cfg, S, ctx, sample_pairs, threads):
     """The CPU port of the reference path (oracle/clip_oracle.py, fp32, torch CPU ops) on the host cores:
     forward + loss + backward + AdamW on a bounded sample of the same workload."""
@@ -61,10 +74,10 @@ def cpu_baseline(cfg, S, ctx, sample_pairs, threads):
         return float(loss)
 
     step()                                          # warm-up
-    t0 = time.perf_counter()
-    n = 2
-    for _ in range(n):
+    n, t0 = 0, time.perf_counter()
+    while n < 2 or (time.perf_counter() - t0 < 10.0 and n < 8):
         step()
+        n += 1
     dt = (time.perf_counter() - t0) / n
     return {"value": sample_pairs / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
             "sample": f"{sample_pairs} pairs/step x {n} timed steps (+1 warm-up), fp32 fwd+loss+bwd+AdamW, "
@@ -83,7 +96,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "amp_bf16"],
                     help="bf16 = reference 'bf16' mode (bf16 weights); amp_bf16 = fp32 master weights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=4)
+    ap.add_argument("--cpu-sample", type=int, default=8, help="pairs per CPU-baseline step")
+    ap.add_argument("--cpu-timeout", type=int, default=240)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -203,8 +217,23 @@ def main():
                             "tflops": round(v["work"] / max(v["ms"], 1e-9) / 1e9, 1)} for k, v in prof.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            threads = os.cpu_count() or 1
-            line["cpu_baseline"] = cpu_baseline(cfg, args.image_size, args.ctx, args.cpu_sample, threads)
+            # bounded: run in a child process with a wall-clock limit so the bench line is never held hostage
+            import subprocess
+            threads = usable_cores()
+            code = ("import json,sys; sys.path.insert(0, %r); import bench, clipa_amd; "
+                    "cfg = clipa_amd.get_model_config(%r); cfg['vision_cfg']['image_size'] = %d; "
+                    "cfg['text_cfg']['context_length'] = %d; "
+                    "print('CPUBASE ' + json.dumps(bench.cpu_baseline(cfg, %d, %d, %d, %d)))"
+                    % (ROOT, args.model, args.image_size, args.ctx, args.image_size, args.ctx, args.cpu_sample, threads))
+            try:
+                r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=args.cpu_timeout,
+                                   env={**os.environ, "HIP_VISIBLE_DEVICES": "", "OMP_NUM_THREADS": str(threads)})
+                got = [l for l in r.stdout.splitlines() if l.startswith("CPUBASE ")]
+                line["cpu_baseline"] = json.loads(got[-1][8:]) if got else {"value": None, "unit": "pairs/s", "cores": threads,
+                                                                           "kind": "port", "sample": "failed: " + r.stderr[-200:]}
+            except subprocess.TimeoutExpired:
+                line["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": threads, "kind": "port",
+                                        "sample": f"timed out after {args.cpu_timeout}s ({args.cpu_sample} pairs/step)"}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

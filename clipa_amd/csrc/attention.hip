@@ -68,10 +68,10 @@ __device__ __forceinline__ bf16x8 frag_trans(const char* img, int rowbase16, int
 }
 
 __device__ __forceinline__ bf16x8 pack_frag(const float* v) {
-  bf16x8 f;
+  u32x4 w;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) f[i] = (short)f2bf(v[i]);
-  return f;
+  for (int i = 0; i < 4; ++i) w[i] = pack2bf(v[2 * i], v[2 * i + 1]);
+  return __builtin_bit_cast(bf16x8, w);
 }
 
 // store a 32x32 fragment held as X^T[d][row] (lane: row = l31, d = 8*(r>>2)+4*hi+(r&3)) into a
@@ -84,6 +84,42 @@ __device__ __forceinline__ void store_frag_T(char* base, long ld, long row, int 
     w[1] = pack2bf(a[4 * qd + 2] * mul, a[4 * qd + 3] * mul);
     *(u32x2*)(base + (row * ld + col0 + 8 * qd + 4 * hi) * 2) = w;
   }
+}
+
+// Row softmax over the transposed score fragments of one 32-query tile.  In: raw q.k scores.  Out: s =
+// exp2(c*(s - rowmax)) (un-normalised, c = scale*log2 e folded into one FMA), inv = 1/rowsum, m2 = c*rowmax.
+// key(kt, r) = 32kt + 8(r>>2) + (r&3) + 4hi is valid iff < lim (padding / causal bound); tiles valid for
+// every lane (wave-uniform test) skip the compare/select.
+template <int NKT>
+__device__ __forceinline__ void softmax_rows(f32x16 (&s)[NKT], const AttnArgs& p, int qt, int qg, int hi,
+                                             float& inv, float& m2) {
+  const float c = p.scale * 1.4426950408889634f;
+  const int lim2 = (p.causal ? min(p.L, qg + 1) : p.L) - 4 * hi;
+  float mx = -1e30f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    const bool full = (32 * kt + 32 <= p.L) && (!p.causal || kt < qt);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = s[kt][r];
+      if (!full) v = (32 * kt + 8 * (r >> 2) + (r & 3) < lim2) ? v : -1e30f;
+      s[kt][r] = v;
+      mx = fmaxf(mx, v);
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  m2 = mx * c;
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c, -m2));
+      s[kt][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  inv = 1.0f / sum;
 }
 
 template <int NKT>
@@ -124,29 +160,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       for (int ks = 0; ks < 4; ++ks)
         s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(sK, 32 * kt, l31, hi, ks), fq[ks], s[kt], 0, 0, 0);
     }
-    float mx = -1e30f;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = 32 * kt + 8 * (r >> 2) + 4 * hi + (r & 3);
-        const bool valid = key < p.L && (!p.causal || key <= qg);
-        const float v = valid ? s[kt][r] * p.scale : -1e30f;
-        s[kt][r] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __expf(s[kt][r] - mx);
-        s[kt][r] = e;
-        sum += e;
-      }
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
+    float inv, m2;
+    softmax_rows<NKT>(s, p, qt, qg, hi, inv, m2);
 
     f32x16 o[2];
 #pragma unroll
@@ -238,30 +253,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
       for (int ks = 0; ks < 4; ++ks)
         s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(sK, 32 * kt, l31, hi, ks), fq[ks], s[kt], 0, 0, 0);
     }
-    float mx = -1e30f;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = 32 * kt + 8 * (r >> 2) + 4 * hi + (r & 3);
-        const bool valid = key < p.L && (!p.causal || key <= qg);
-        const float v = valid ? s[kt][r] * p.scale : -1e30f;
-        s[kt][r] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __expf(s[kt][r] - mx);
-        s[kt][r] = e;
-        sum += e;
-      }
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-    if (hi == 0) { sM[qg] = mx; sL[qg] = inv; }
+    float inv, m2;
+    softmax_rows<NKT>(s, p, qt, qg, hi, inv, m2);
+    if (hi == 0) { sM[qg] = m2; sL[qg] = inv; }
     const float Dq = sD[qg];
 
     f32x16 dq[2];
@@ -300,6 +294,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
   // ---- sweep 2: key-major, dK and dV -----------------------------------------------------------
   for (int kt = wave; kt < NKT; kt += 4) {
     const int kg = 32 * kt + l31;
+    const int kgc = l31 - 4 * hi;      // causal test inside the diagonal tile: key <= query
+    const float c2 = p.scale * 1.4426950408889634f;
     bf16x8 fk[4], fv[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -333,9 +329,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * rq + e;
-          const int qg = q0 + e;
-          const bool valid = kg < p.L && (!p.causal || kg <= qg);
-          const float pe = valid ? __expf(s[r] * p.scale - mm[e]) * ll[e] : 0.f;
+          // query index = 32qt + 8rq + e + 4hi.  Padded keys (kg >= L) need no mask: their K/V rows are
+          // zero, the lane's column is never stored and never mixes into other lanes' columns.
+          float pe = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -mm[e])) * ll[e];
+          if (p.causal && qt == kt) pe = (kgc <= 8 * rq + e) ? pe : 0.f;
           pr[r] = pe;
           ds[r] = pe * (dp[r] - dd[e]) * p.scale;
         }

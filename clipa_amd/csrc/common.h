@@ -25,15 +25,16 @@ int clipa_check_launch(const char* what);
 __device__ __forceinline__ float bf2f(unsigned short h) {
   return __uint_as_float(((unsigned int)h) << 16);
 }
-// round-to-nearest-even; NaN stays NaN
-__device__ __forceinline__ unsigned short f2bf(float f) {
-  unsigned int u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
+// round-to-nearest-even via the gfx950 hardware converter (v_cvt_pk_bf16_f32: one VALU op per pair)
+typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;
 __device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
-  return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+  hw_bf16x2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned int, v);
+}
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  return __builtin_bit_cast(unsigned short, (__bf16)f);
 }
 __device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
 #pragma unroll

@@ -18,6 +18,7 @@
 // operands.  Tile ids are remapped so each XCD's L2 sees a contiguous run of tiles.
 #include "common.h"
 #include "clipa_hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -204,6 +205,250 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(NTArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_nt v2: PERSISTENT tiles.  One workgroup per CU walks its share of the output tiles; the DMA
+// ring never drains (the first K tile of the next output tile is fetched while the last K tile of
+// the current one computes), MFMA operand fragments are register-prefetched one k-step ahead, and
+// the epilogue goes through a dedicated 32 KiB LDS window (4 passes of 64 rows) placed after the
+// 128 KiB ring, so its global stores retire underneath the next tile's main loop.
+constexpr int CBUF_OFF = 2 * STAGE_BYTES;            // 131072
+constexpr int LDS2_BYTES = CBUF_OFF + 64 * 512;      // 163840 = all 160 KiB of the CU
+
+template <int ACT>
+__device__ __forceinline__ u32x4 epi_chunk(int epi, u32x4 v, u32x4 av) {
+  float f[8], a[8];
+  unpack8(v, f);
+  unpack8(av, a);
+  if (epi == CLIPA_EPI_ADD) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] += a[i];
+  } else {
+    epi_apply<ACT>(epi, f, a);
+  }
+  return pack8(f);
+}
+
+template <bool OUT_F32, bool SETPRIO>
+__global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const int tilesN = (p.N + BN - 1) / BN;
+  const int tilesM = (p.M + BM - 1) / BM;
+  const unsigned ntiles = (unsigned)(tilesM * tilesN);
+  // XCD x (blocks with bid%8 == x) owns the contiguous tile range [base, base+len); its workgroups
+  // take consecutive tiles, so the N-tiles of one A panel run side by side under one L2.
+  const unsigned G = gridDim.x, xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+  const unsigned gx = (G - xcd + 7u) >> 3;            // workgroups on this XCD
+  const unsigned q8 = ntiles >> 3, r8 = ntiles & 7u;
+  const unsigned base = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const unsigned len = q8 + (xcd < r8 ? 1u : 0u);
+
+  unsigned voffA[4], voffB[4];
+  int kel[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (j * 8 + wave) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    voffA[j] = (unsigned)(row * p.lda * 2 + chunk * 16);
+    voffB[j] = (unsigned)(row * p.ldb * 2 + chunk * 16);
+    kel[j] = chunk * 8;
+  }
+  const int sw = (l31 >> 1) & 7;
+  const int rowoffA = (wm * 128 + l31) * 128;
+  const int rowoffB = (wn * 64 + l31) * 128;
+  const int nkt = (p.K + BK - 1) / BK;
+
+  auto tile_origin = [&](unsigned t, int& m0, int& n0) {
+    const int tm = (int)(t / (unsigned)tilesN);
+    m0 = tm * BM;
+    n0 = ((int)t - tm * tilesN) * BN;
+  };
+  auto stage = [&](int buf, int m0, int n0, int k0) {
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A + (size_t)m0 * p.lda * 2, (unsigned)(min(BM, p.M - m0) * p.lda * 2));
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B + (size_t)n0 * p.ldb * 2, (unsigned)(min(BN, p.N - n0) * p.ldb * 2));
+    char* sA = smem + buf * STAGE_BYTES;
+    char* sB = sA + IMG_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int pc = j * 8 + wave;
+      const unsigned oob = (k0 + kel[j] >= p.K) ? 0x80000000u : 0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(sA + pc * 1024), 16, voffA[j] | oob, k0 * 2, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(sB + pc * 1024), 16, voffB[j] | oob, k0 * 2, 0, 0);
+    }
+  };
+
+  if (idx >= len) return;
+  unsigned it = idx;
+  int m0, n0;
+  tile_origin(base + it, m0, n0);
+  stage(0, m0, n0, 0);
+  unsigned gk = 0;   // global K-tile counter: ring slot = gk & 1
+  for (;;) {
+    const bool has_next = it + gx < len;
+    int m1 = 0, n1 = 0;
+    if (has_next) tile_origin(base + it + gx, m1, n1);
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+
+    for (int kt = 0; kt < nkt; ++kt, ++gk) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < nkt) stage((gk + 1) & 1, m0, n0, (kt + 1) * BK);
+      else if (has_next) stage((gk + 1) & 1, m1, n1, 0);
+      const char* sA = smem + (gk & 1) * STAGE_BYTES;
+      const char* sB = sA + IMG_BYTES;
+      bf16x8 fa[2][4], fb[2][2];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) fa[0][mi] = *(const bf16x8*)(sA + rowoffA + mi * 4096 + ((hi ^ sw) << 4));
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) fb[0][ni] = *(const bf16x8*)(sB + rowoffB + ni * 4096 + ((hi ^ sw) << 4));
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks < 3) {
+          const int coff = ((2 * (ks + 1) + hi) ^ sw) << 4;
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) fa[nxt][mi] = *(const bf16x8*)(sA + rowoffA + mi * 4096 + coff);
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) fb[nxt][ni] = *(const bf16x8*)(sB + rowoffB + ni * 4096 + coff);
+        }
+        if (SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][ni], fa[cur][mi], acc[ni][mi], 0, 0, 0);
+        if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+      }
+    }
+
+    // ---- epilogue of tile (m0, n0); the ring keeps filling for the next tile meanwhile ----
+    if (OUT_F32) {
+      float* C = (float*)p.C;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const int m = m0 + wm * 128 + mi * 32 + l31;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int n = n0 + wn * 64 + ni * 32 + 8 * q + 4 * hi;
+            if (m < p.M && n < p.N) {
+              float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (p.bias) b4 = *(const float4*)(p.bias + n);
+              float4 o;
+              o.x = acc[ni][mi][4 * q + 0] * p.alpha + b4.x;
+              o.y = acc[ni][mi][4 * q + 1] * p.alpha + b4.y;
+              o.z = acc[ni][mi][4 * q + 2] * p.alpha + b4.z;
+              o.w = acc[ni][mi][4 * q + 3] * p.alpha + b4.w;
+              *(float4*)(C + (size_t)m * p.ldc + n) = o;
+            }
+          }
+        }
+    } else {
+      char* cb = smem + CBUF_OFF;
+      const int epi = p.epi, act = p.act;
+      float4 bias4[2][4];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn * 64 + ni * 32 + 8 * q + 4 * hi;
+          bias4[ni][q] = (p.bias && n < p.N) ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      // this thread's chunks of a pass: chunk c = j*512 + tid -> row c>>5 (0..63), 16-B column c&31.
+      // aux (residual / pre-activation) chunks are fetched two passes at a time, ahead of their use.
+      u32x4 av[8];
+      auto fetch_aux = [&](int pass0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          av[i] = u32x4{0, 0, 0, 0};
+          const int c = (i & 3) * NTHREADS + tid;
+          const int m = m0 + (pass0 + (i >> 2)) * 64 + (c >> 5), n = n0 + (c & 31) * 8;
+          if ((epi == CLIPA_EPI_ADD || epi == CLIPA_EPI_DACT) && m < p.M && n < p.N)
+            av[i] = *(const u32x4*)(p.aux + ((size_t)m * p.ldaux + n) * 2);
+        }
+      };
+      // LDS-only barriers: a full __syncthreads() would also wait (vmcnt) for the previous pass's global stores
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        if ((pass & 1) == 0) fetch_aux(pass);
+        LDS_BARRIER();   // readers of the previous pass are done with the window
+        if (wm == (pass >> 1)) {
+#pragma unroll
+          for (int mi2 = 0; mi2 < 2; ++mi2) {
+            const int mi = 2 * (pass & 1) + mi2;
+            const int row = mi2 * 32 + l31;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int nl = wn * 64 + ni * 32 + 8 * q + 4 * hi;
+                const float4 b4 = bias4[ni][q];
+                u32x2 w;
+                w[0] = pack2bf(acc[ni][mi][4 * q + 0] * p.alpha + b4.x, acc[ni][mi][4 * q + 1] * p.alpha + b4.y);
+                w[1] = pack2bf(acc[ni][mi][4 * q + 2] * p.alpha + b4.z, acc[ni][mi][4 * q + 3] * p.alpha + b4.w);
+                *(u32x2*)(cb + row * 512 + ((((nl >> 3) ^ row) & 31) << 4) + (nl & 7) * 2) = w;
+              }
+          }
+        }
+        LDS_BARRIER();
+        // The window is read with inline-asm ds_read_b128: with an LDS-DMA possibly in flight hipcc puts
+        // `s_waitcnt vmcnt(0)` in front of every compiler-visible LDS read, which would serialise each
+        // pass behind the global stores of the previous one.  (Hidden loads: waited for by hand, §5.7.)
+        u32x4 cv[4];
+        {
+          unsigned a[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int c = j * NTHREADS + tid;
+            const int row = c >> 5, cc = c & 31;
+            a[j] = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(cb + row * 512 + (((cc ^ row) & 31) << 4));
+          }
+          asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\t"
+                       "s_waitcnt lgkmcnt(0)"
+                       : "=&v"(cv[0]), "=&v"(cv[1]), "=&v"(cv[2]), "=&v"(cv[3])
+                       : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3])
+                       : "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = j * NTHREADS + tid;
+          const int row = c >> 5, cc = c & 31;
+          const int m = m0 + pass * 64 + row, n = n0 + cc * 8;
+          if (m < p.M && n < p.N) {
+            u32x4 v = cv[j];
+            if (epi == CLIPA_EPI_ACT && p.C2) *(u32x4*)(p.C2 + ((size_t)m * p.ldc + n) * 2) = v;
+            if (epi != CLIPA_EPI_NONE) {
+              if (act == ACT_GELU_ERF) v = epi_chunk<ACT_GELU_ERF>(epi, v, av[(pass & 1) * 4 + j]);
+              else if (act == ACT_GELU_TANH) v = epi_chunk<ACT_GELU_TANH>(epi, v, av[(pass & 1) * 4 + j]);
+              else v = epi_chunk<ACT_QUICK_GELU>(epi, v, av[(pass & 1) * 4 + j]);
+            }
+            *(u32x4*)(p.C + ((size_t)m * p.ldc + n) * 2) = v;
+          }
+        }
+      }
+#undef LDS_BARRIER
+    }
+    if (!has_next) break;
+    it += gx;
+    m0 = m1;
+    n0 = n1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 struct TNArgs {
   const char* P; const char* Q; float* O;
   int M, R, C;
@@ -351,6 +596,8 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, void* __res
 }
 
 bool g_attr_done = false;
+int g_num_cu = 256;
+int g_nt_variant = 2;
 int ensure_attrs() {
   if (g_attr_done) return 0;
   hipError_t e;
@@ -360,6 +607,16 @@ int ensure_attrs() {
   if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_nt<f32>): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
   e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
   if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_tn): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
+  const void* v2[4] = {(const void*)gemm_nt2_kernel<false, false>, (const void*)gemm_nt2_kernel<false, true>,
+                       (const void*)gemm_nt2_kernel<true, false>, (const void*)gemm_nt2_kernel<true, true>};
+  for (int i = 0; i < 4; ++i) {
+    e = hipFuncSetAttribute(v2[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES);
+    if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_nt2): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
+  }
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cu = prop.multiProcessorCount;
+  if (const char* v = getenv("CLIPA_GEMM_NT")) g_nt_variant = atoi(v);   // 1 = one tile per workgroup, 2 = persistent, 3 = persistent + setprio
   g_attr_done = true;
   return 0;
 }
@@ -382,8 +639,18 @@ extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, co
   a.M = (int)M; a.N = (int)N; a.K = (int)K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
   a.alpha = alpha; a.epi = epi; a.act = act;
   const long tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-  if (out_f32) hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3((unsigned)tiles), dim3(NTHREADS), LDS_BYTES, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(gemm_nt_kernel<false>, dim3((unsigned)tiles), dim3(NTHREADS), LDS_BYTES, (hipStream_t)stream, a);
+  hipStream_t st = (hipStream_t)stream;
+  if (g_nt_variant >= 2) {
+    const unsigned grid = (unsigned)(tiles < g_num_cu ? tiles : g_num_cu);
+    const bool prio = g_nt_variant == 3;
+    if (out_f32 && prio) hipLaunchKernelGGL((gemm_nt2_kernel<true, true>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
+    else if (out_f32) hipLaunchKernelGGL((gemm_nt2_kernel<true, false>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
+    else if (prio) hipLaunchKernelGGL((gemm_nt2_kernel<false, true>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
+    else hipLaunchKernelGGL((gemm_nt2_kernel<false, false>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
+    return clipa_check_launch("gemm_nt2");
+  }
+  if (out_f32) hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3((unsigned)tiles), dim3(NTHREADS), LDS_BYTES, st, a);
+  else hipLaunchKernelGGL(gemm_nt_kernel<false>, dim3((unsigned)tiles), dim3(NTHREADS), LDS_BYTES, st, a);
   return clipa_check_launch("gemm_nt");
 }
 

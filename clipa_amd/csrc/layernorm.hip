@@ -187,22 +187,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
 }
 
 // out[which][col] = sum_b part[which][b][col]
-__global__ void ln_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, int nblk, int D) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= D) return;
-  float a = 0.f, b = 0.f;
-  for (int s = 0; s < nblk; ++s) {
-    a += part[(size_t)s * D + col];
-    b += part[((size_t)nblk + s) * D + col];
+// 64 columns per block, 4 waves striding the partial rows (4 independent loads in flight per lane)
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int nblk, int D) {
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+  if (col < D) {
+    int s = grp;
+    for (; s + 4 < nblk; s += 8) {
+      a0 += part[(size_t)s * D + col];
+      a1 += part[(size_t)(s + 4) * D + col];
+      b0 += part[((size_t)nblk + s) * D + col];
+      b1 += part[((size_t)nblk + s + 4) * D + col];
+    }
+    for (; s < nblk; s += 4) {
+      a0 += part[(size_t)s * D + col];
+      b0 += part[((size_t)nblk + s) * D + col];
+    }
   }
-  dgamma[col] = a;
-  dbeta[col] = b;
+  red[0][grp][lane] = a0 + a1;
+  red[1][grp][lane] = b0 + b1;
+  __syncthreads();
+  if (grp == 0 && col < D) {
+    dgamma[col] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+    dbeta[col] = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+  }
 }
 
-int ln_grid(long rows) {
+int ln_grid(long rows, long cap = 2048) {
   long g = (rows + 3) / 4;
-  if (g > 2048) g = 2048;
+  if (g > cap) g = cap;
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -241,7 +257,7 @@ extern "C" int clipa_layernorm_fwd(const void* x, const float* gamma, const floa
 }
 
 extern "C" int64_t clipa_layernorm_bwd_workspace(int64_t rows, int64_t D) {
-  return (int64_t)2 * ln_grid(rows) * D * sizeof(float);
+  return (int64_t)2 * ln_grid(rows, 1024) * D * sizeof(float);
 }
 
 extern "C" int clipa_layernorm_bwd(const void* x, const float* gamma, const void* dy, const void* dres,
@@ -252,13 +268,13 @@ extern "C" int clipa_layernorm_bwd(const void* x, const float* gamma, const void
   if (rows <= 0) return CLIPA_OK;
   if (!workspace || workspace_bytes < clipa_layernorm_bwd_workspace(rows, D)) { clipa_set_error("layernorm_bwd: workspace too small"); return CLIPA_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
-  const int grid = ln_grid(rows);
+  const int grid = ln_grid(rows, 1024);
   float* part = (float*)workspace;
   if (D <= 512) launch_bwd<1>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, st);
   else if (D <= 1024) launch_bwd<2>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, st);
   else if (D <= 1536) launch_bwd<3>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, st);
   else launch_bwd<4>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, st);
   if (int rc = clipa_check_launch("layernorm_bwd")) return rc;
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, part, dgamma, dbeta, grid, (int)D);
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((D + 63) / 64)), dim3(256), 0, st, part, dgamma, dbeta, grid, (int)D);
   return clipa_check_launch("layernorm_bwd_reduce");
 }

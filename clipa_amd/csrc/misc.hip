@@ -287,12 +287,23 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const unsigned shor
     if (c < N) part[(size_t)blockIdx.y * N + c] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
   }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int N) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= N) return;
-  float a = 0.f;
-  for (int s = 0; s < nblk; ++s) a += part[(size_t)s * N + c];
-  out[c] = a;
+// 64 columns per block, 4 waves striding the partial rows
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int N) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < N) {
+    int s = grp;
+    for (; s + 4 < nblk; s += 8) {
+      a0 += part[(size_t)s * N + c];
+      a1 += part[(size_t)(s + 4) * N + c];
+    }
+    for (; s < nblk; s += 4) a0 += part[(size_t)s * N + c];
+  }
+  red[grp][lane] = a0 + a1;
+  __syncthreads();
+  if (grp == 0 && c < N) out[c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -546,7 +557,7 @@ extern "C" int clipa_colsum(const void* dy, float* out, int64_t M, int64_t N, in
   const int nb2 = (int)((M + rpb - 1) / rpb);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((N + 511) / 512), (unsigned)nb2), dim3(256), 0, st, (const unsigned short*)dy, (float*)workspace, (long)M, (int)N, (long)ld, rpb);
   if (int rc = clipa_check_launch("colsum_partial")) return rc;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, (const float*)workspace, out, nb2, (int)N);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, st, (const float*)workspace, out, nb2, (int)N);
   return clipa_check_launch("colsum_final");
 }
 

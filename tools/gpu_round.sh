@@ -24,6 +24,18 @@ for s in $STAGES; do
       echo "rc=$?" >> gpurun_out/bench_small.log ;;
     bench)
       timeout 1500 python bench.py > gpurun_out/bench.log 2>&1; echo "rc=$?" >> gpurun_out/bench.log ;;
+    pmc)
+      # hardware counters for the dominant GEMM shape (own passes, no trace domains mixed in)
+      mkdir -p gpurun_out/pmc
+      R="$PWD"
+      for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+                 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE" \
+                 "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+        tag=$(echo $set | cut -d' ' -f1)
+        (cd /tmp && timeout 300 rocprofv3 --pmc $set -d "$R/gpurun_out/pmc/$tag" -o pmc -- \
+           python "$R/tools/gemm_probe.py" nt 65536 4096 1024 bias 3 > "$R/gpurun_out/pmc/$tag.log" 2>&1)
+      done
+      python tools/pmc_summary.py gpurun_out/pmc > gpurun_out/pmc_summary.txt 2>&1 ;;
     prof)
       mkdir -p gpurun_out/prof
       (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o r01 -- \
