@@ -35,6 +35,7 @@ struct NTArgs {
   long lda, ldb, ldc, ldaux;   // element strides
   float alpha;
   int epi, act;
+  int abl;   // ablation flags for kernel experiments (CLIPA_GEMM_ABL): 1 no global stores, 2 no epilogue, 4 no bias loads
 };
 
 template <int ACT>
@@ -333,7 +334,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
     }
 
     // ---- epilogue of tile (m0, n0); the ring keeps filling for the next tile meanwhile ----
-    if (OUT_F32) {
+    if (p.abl & 2) {   // ablation: keep the accumulators live, write nothing
+      float t = 0.f;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t += acc[ni][mi][r];
+      if (t == 1.2345e-30f) ((float*)p.C)[tid] = t;
+    } else if (OUT_F32) {
       float* C = (float*)p.C;
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
@@ -364,7 +374,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int n = n0 + wn * 64 + ni * 32 + 8 * q + 4 * hi;
-          bias4[ni][q] = (p.bias && n < p.N) ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+          bias4[ni][q] = (p.bias && n < p.N && !(p.abl & 4)) ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       // this thread's chunks of a pass: chunk c = j*512 + tid -> row c>>5 (0..63), 16-B column c&31.
       // aux (residual / pre-activation) chunks are fetched two passes at a time, ahead of their use.
@@ -427,7 +437,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
           const int c = j * NTHREADS + tid;
           const int row = c >> 5, cc = c & 31;
           const int m = m0 + pass * 64 + row, n = n0 + cc * 8;
-          if (m < p.M && n < p.N) {
+          if (m < p.M && n < p.N && !((p.abl & 1) && cv[j][0] != 0x12345u)) {
             u32x4 v = cv[j];
             if (epi == CLIPA_EPI_ACT && p.C2) *(u32x4*)(p.C2 + ((size_t)m * p.ldc + n) * 2) = v;
             if (epi != CLIPA_EPI_NONE) {
@@ -598,6 +608,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, void* __res
 bool g_attr_done = false;
 int g_num_cu = 256;
 int g_nt_variant = 2;
+int g_abl = 0;
 int ensure_attrs() {
   if (g_attr_done) return 0;
   hipError_t e;
@@ -616,7 +627,8 @@ int ensure_attrs() {
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cu = prop.multiProcessorCount;
-  if (const char* v = getenv("CLIPA_GEMM_NT")) g_nt_variant = atoi(v);   // 1 = one tile per workgroup, 2 = persistent, 3 = persistent + setprio
+  if (const char* v = getenv("CLIPA_GEMM_NT")) g_nt_variant = atoi(v);
+  if (const char* v = getenv("CLIPA_GEMM_ABL")) g_abl = atoi(v);   // 1 = one tile per workgroup, 2 = persistent, 3 = persistent + setprio
   g_attr_done = true;
   return 0;
 }
@@ -637,7 +649,7 @@ extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, co
   NTArgs a;
   a.A = (const char*)A; a.B = (const char*)B; a.C = (char*)C; a.C2 = (char*)C2; a.bias = bias; a.aux = (const char*)aux;
   a.M = (int)M; a.N = (int)N; a.K = (int)K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
-  a.alpha = alpha; a.epi = epi; a.act = act;
+  a.alpha = alpha; a.epi = epi; a.act = act; a.abl = g_abl;
   const long tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   hipStream_t st = (hipStream_t)stream;
   if (g_nt_variant >= 2) {
