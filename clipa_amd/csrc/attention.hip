@@ -24,6 +24,7 @@ struct AttnArgs {
   const char* q; const char* k; const char* v; long ld_qkv;   // bf16 rows, stride in elements
   char* o; const char* o_in; const char* d_o; long ld_o;
   char* dq; char* dk; char* dv; long ld_dqkv;
+  float* stats;   // [B*H*L][2] = (c*rowmax, 1/rowsum), written by fwd, read by bwd
   int B, H, L;
   float scale;
   int causal;
@@ -186,19 +187,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
         store_frag_T(p.o, p.ld_o, (long)b * p.L + qg, h * 64 + 32 * dt, hi, o[dt], inv);
+      if (p.stats && hi == 0) *(float2*)(p.stats + ((size_t)blockIdx.x * p.L + qg) * 2) = make_float2(m2, inv);
     }
   }
 }
 
+// load the 4 k-step fragments of one 32-row tile straight from global memory (rows >= L read zeros)
+__device__ __forceinline__ void load_frags(const __amdgpu_buffer_rsrc_t rs, long ld, int row, int hi, bf16x8 (&f)[4]) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    f[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(row * ld * 2 + (2 * ks + hi) * 16), 0, 0));
+}
+
+// Backward.  Two LDS phases share one 2-image window (so two workgroups fit per CU):
+//   phase 1: K, V images; query-major sweep -> dQ   (q / dO / O rows of the wave's tile come from global)
+//   phase 2: Q, dO images; key-major sweep   -> dK, dV (k / v rows of the wave's tile come from global)
+// Probabilities are recomputed from the forward's (c*rowmax, 1/rowsum) statistics; D_q = <dO_q, O_q>.
 template <int NKT>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   constexpr int LP = NKT * 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sQ = smem;
-  char* sK = smem + LP * 128;
-  char* sV = smem + 2 * LP * 128;
-  char* sDO = smem + 3 * LP * 128;
-  float* sM = (float*)(smem + 4 * LP * 128);
+  char* img0 = smem;
+  char* img1 = smem + LP * 128;
+  float* sM = (float*)(smem + 2 * LP * 128);
   float* sL = sM + LP;
   float* sD = sL + LP;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -209,55 +220,37 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
   const size_t ooff = ((size_t)b * p.L * p.ld_o + (size_t)h * 64) * 2;
   const unsigned nrec = (unsigned)((long)(p.L - 1) * p.ld_qkv * 2 + 128);
   const unsigned nrec_o = (unsigned)((long)(p.L - 1) * p.ld_o * 2 + 128);
-  dma_image(make_rsrc(p.q + hoff, nrec), sQ, LP, p.ld_qkv, wave, lane);
-  dma_image(make_rsrc(p.k + hoff, nrec), sK, LP, p.ld_qkv, wave, lane);
-  dma_image(make_rsrc(p.v + hoff, nrec), sV, LP, p.ld_qkv, wave, lane);
-  dma_image(make_rsrc(p.d_o + ooff, nrec_o), sDO, LP, p.ld_o, wave, lane);
+  const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.q + hoff, nrec), rsK = make_rsrc(p.k + hoff, nrec),
+                               rsV = make_rsrc(p.v + hoff, nrec), rsDO = make_rsrc(p.d_o + ooff, nrec_o),
+                               rsO = make_rsrc(p.o_in + ooff, nrec_o);
+  const float c = p.scale * 1.4426950408889634f;
+  const float* stats = p.stats + (size_t)blockIdx.x * p.L * 2;
+
+  // ---- phase 1: dQ ------------------------------------------------------------------------------
+  dma_image(rsK, img0, LP, p.ld_qkv, wave, lane);
+  dma_image(rsV, img1, LP, p.ld_qkv, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-
-  // D_q = sum_d dO[q][d] * O[q][d]  (= sum_k P dP), one thread per query
-  for (int qq = tid; qq < LP; qq += 256) {
-    float acc = 0.f;
-    if (qq < p.L) {
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        float a[8], o8[8];
-        unpack8(*(const u32x4*)(sDO + qq * 128 + c * 16), a);
-        const int lc = c ^ swz_u(qq);
-        unpack8(*(const u32x4*)(p.o_in + ooff + ((size_t)qq * p.ld_o) * 2 + lc * 16), o8);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc += a[i] * o8[i];
-      }
-    }
-    sD[qq] = acc;
-  }
-  __syncthreads();
-
-  // ---- sweep 1: query-major, dQ --------------------------------------------------------------
   for (int qt = wave; qt < NKT; qt += 4) {
     const int qg = 32 * qt + l31;
-    bf16x8 fq[4], fdo[4];
+    bf16x8 fq[4], fdo[4], fo[4];
+    load_frags(rsQ, p.ld_qkv, qg, hi, fq);
+    load_frags(rsDO, p.ld_o, qg, hi, fdo);
+    load_frags(rsO, p.ld_o, qg, hi, fo);
+    float2 st = make_float2(0.f, 0.f);                 // padded queries: inv = 0 -> P = 0
+    if (qg < p.L) st = *(const float2*)(stats + qg * 2);
+    float Dq = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      fq[ks] = frag_direct(sQ, 32 * qt, l31, hi, ks);
-      fdo[ks] = frag_direct(sDO, 32 * qt, l31, hi, ks);
+      float a[8], o8[8];
+      unpack8(__builtin_bit_cast(u32x4, fdo[ks]), a);
+      unpack8(__builtin_bit_cast(u32x4, fo[ks]), o8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) Dq += a[i] * o8[i];
     }
-    f32x16 s[NKT];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-      if (p.causal && kt > qt) continue;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(sK, 32 * kt, l31, hi, ks), fq[ks], s[kt], 0, 0, 0);
-    }
-    float inv, m2;
-    softmax_rows<NKT>(s, p, qt, qg, hi, inv, m2);
-    if (hi == 0) { sM[qg] = m2; sL[qg] = inv; }
-    const float Dq = sD[qg];
-
+    Dq += __shfl_xor(Dq, 32, 64);
+    if (hi == 0) { sM[qg] = st.x; sL[qg] = st.y; sD[qg] = Dq; }
+    const int lim2 = (p.causal ? min(p.L, qg + 1) : p.L) - 4 * hi;
     f32x16 dq[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -266,21 +259,28 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       if (p.causal && kt > qt) continue;
-      f32x16 dp;
+      f32x16 s, dp;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(sV, 32 * kt, l31, hi, ks), fdo[ks], dp, 0, 0, 0);
+      for (int ks = 0; ks < 4; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(img0, 32 * kt, l31, hi, ks), fq[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(img1, 32 * kt, l31, hi, ks), fdo[ks], dp, 0, 0, 0);
+      }
+      const bool full = (32 * kt + 32 <= p.L) && (!p.causal || kt < qt);
+      float ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float pe = __builtin_amdgcn_exp2f(fmaf(s[r], c, -st.x)) * st.y;
+        if (!full) pe = (32 * kt + 8 * (r >> 2) + (r & 3) < lim2) ? pe : 0.f;
+        ds[r] = pe * (dp[r] - Dq) * p.scale;
+      }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        float dsv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dsv[e] = s[kt][8 * s2 + e] * inv * (dp[8 * s2 + e] - Dq) * p.scale;
-        const bf16x8 dsf = pack_frag(dsv);
+        const bf16x8 dsf = pack_frag(ds + 8 * s2);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
-          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans(sK, 32 * kt + 16 * s2, 32 * dt, hi, q16, i16), dsf, dq[dt], 0, 0, 0);
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans(img0, 32 * kt + 16 * s2, 32 * dt, hi, q16, i16), dsf, dq[dt], 0, 0, 0);
       }
     }
     if (qg < p.L) {
@@ -289,19 +289,19 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
         store_frag_T(p.dq, p.ld_dqkv, (long)b * p.L + qg, h * 64 + 32 * dt, hi, dq[dt], 1.0f);
     }
   }
-  __syncthreads();
+  __syncthreads();   // everyone is done with the K / V images (and the statistics are in LDS)
 
-  // ---- sweep 2: key-major, dK and dV -----------------------------------------------------------
+  // ---- phase 2: dK, dV --------------------------------------------------------------------------
+  dma_image(rsQ, img0, LP, p.ld_qkv, wave, lane);
+  dma_image(rsDO, img1, LP, p.ld_o, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   for (int kt = wave; kt < NKT; kt += 4) {
     const int kg = 32 * kt + l31;
     const int kgc = l31 - 4 * hi;      // causal test inside the diagonal tile: key <= query
-    const float c2 = p.scale * 1.4426950408889634f;
     bf16x8 fk[4], fv[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      fk[ks] = frag_direct(sK, 32 * kt, l31, hi, ks);
-      fv[ks] = frag_direct(sV, 32 * kt, l31, hi, ks);
-    }
+    load_frags(rsK, p.ld_qkv, kg, hi, fk);
+    load_frags(rsV, p.ld_qkv, kg, hi, fv);
     f32x16 dk[2], dv[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -313,8 +313,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(sQ, 32 * qt, l31, hi, ks), fk[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(sDO, 32 * qt, l31, hi, ks), fv[ks], dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(img0, 32 * qt, l31, hi, ks), fk[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(img1, 32 * qt, l31, hi, ks), fv[ks], dp, 0, 0, 0);
       }
       float pr[16], ds[16];
 #pragma unroll
@@ -329,9 +329,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * rq + e;
-          // query index = 32qt + 8rq + e + 4hi.  Padded keys (kg >= L) need no mask: their K/V rows are
-          // zero, the lane's column is never stored and never mixes into other lanes' columns.
-          float pe = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -mm[e])) * ll[e];
+          // query = 32qt + 8rq + e + 4hi.  Padded queries carry inv = 0; padded keys need no mask: their
+          // K/V rows are zero, their column is never stored and never mixes into other lanes' columns.
+          float pe = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mm[e])) * ll[e];
           if (p.causal && qt == kt) pe = (kgc <= 8 * rq + e) ? pe : 0.f;
           pr[r] = pe;
           ds[r] = pe * (dp[r] - dd[e]) * p.scale;
@@ -343,8 +343,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
         const bf16x8 dsf = pack_frag(ds + 8 * s2);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans(sDO, 32 * qt + 16 * s2, 32 * dt, hi, q16, i16), pf, dv[dt], 0, 0, 0);
-          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans(sQ, 32 * qt + 16 * s2, 32 * dt, hi, q16, i16), dsf, dk[dt], 0, 0, 0);
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans(img1, 32 * qt + 16 * s2, 32 * dt, hi, q16, i16), pf, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans(img0, 32 * qt + 16 * s2, 32 * dt, hi, q16, i16), dsf, dk[dt], 0, 0, 0);
         }
       }
     }
@@ -372,7 +372,7 @@ int launch_fwd(const AttnArgs& a, hipStream_t st) {
 }
 template <int NKT>
 int launch_bwd(const AttnArgs& a, hipStream_t st) {
-  const int lds = 4 * NKT * 32 * 128 + 3 * NKT * 32 * 4;
+  const int lds = 2 * NKT * 32 * 128 + 3 * NKT * 32 * 4;
   static bool done = false;
   if (!done) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -402,28 +402,31 @@ int check_args(int64_t B, int64_t H, int64_t L, int64_t dh, int64_t ld_qkv, int6
     default: return fn<9>(a, st);                                   \
   }
 
-extern "C" int clipa_attention_fwd(const void* q, const void* k, const void* v, void* out, int64_t B,
-                                   int64_t H, int64_t L, int64_t dh, int64_t ld_qkv, int64_t ld_o,
+extern "C" int clipa_attention_fwd(const void* q, const void* k, const void* v, void* out, float* stats,
+                                   int64_t B, int64_t H, int64_t L, int64_t dh, int64_t ld_qkv, int64_t ld_o,
                                    float scale, int causal, void* stream) {
   if (B * H == 0) return CLIPA_OK;
   if (int rc = check_args(B, H, L, dh, ld_qkv, ld_o)) return rc;
   AttnArgs a = {};
   a.q = (const char*)q; a.k = (const char*)k; a.v = (const char*)v; a.ld_qkv = ld_qkv;
   a.o = (char*)out; a.ld_o = ld_o; a.B = (int)B; a.H = (int)H; a.L = (int)L; a.scale = scale; a.causal = causal;
+  a.stats = stats;
   ATTN_DISPATCH(launch_fwd, a, (hipStream_t)stream)
 }
 
 extern "C" int clipa_attention_bwd(const void* q, const void* k, const void* v, const void* out,
-                                   const void* d_out, void* dq, void* dk, void* dv, int64_t B, int64_t H,
+                                   const void* d_out, const float* stats, void* dq, void* dk, void* dv, int64_t B, int64_t H,
                                    int64_t L, int64_t dh, int64_t ld_qkv, int64_t ld_o, int64_t ld_dqkv,
                                    float scale, int causal, void* stream) {
   if (B * H == 0) return CLIPA_OK;
   if (int rc = check_args(B, H, L, dh, ld_qkv, ld_o)) return rc;
   if (ld_dqkv % 8 != 0) { clipa_set_error("attention_bwd: ld_dqkv must be a multiple of 8"); return CLIPA_ERR_ARG; }
+  if (!stats) { clipa_set_error("attention_bwd: needs the forward's softmax statistics"); return CLIPA_ERR_ARG; }
   AttnArgs a = {};
   a.q = (const char*)q; a.k = (const char*)k; a.v = (const char*)v; a.ld_qkv = ld_qkv;
   a.o_in = (const char*)out; a.d_o = (const char*)d_out; a.ld_o = ld_o;
   a.dq = (char*)dq; a.dk = (char*)dk; a.dv = (char*)dv; a.ld_dqkv = ld_dqkv;
   a.B = (int)B; a.H = (int)H; a.L = (int)L; a.scale = scale; a.causal = causal;
+  a.stats = const_cast<float*>(stats);
   ATTN_DISPATCH(launch_bwd, a, (hipStream_t)stream)
 }

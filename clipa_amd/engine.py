@@ -63,7 +63,10 @@ def _block_forward(x, P, cfg, keep):
     B, L, H, causal, act = cfg["B"], cfg["L"], cfg["H"], cfg["causal"], cfg["act"]
     h1 = ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"])
     qkv = ops.gemm_nt(h1, P["w_in"], P["b_in"])
-    a = ops.attention_fwd(qkv, B, L, H, causal)
+    if keep:
+        a, stats = ops.attention_fwd(qkv, B, L, H, causal, want_stats=True)
+    else:
+        a, stats = ops.attention_fwd(qkv, B, L, H, causal), None
     x1 = ops.gemm_nt(a, P["w_out"], P["b_out"], epi=ops.EPI_ADD, aux=x)
     h2 = ops.layernorm_fwd(x1, P["ln2_w"], P["ln2_b"], cfg["eps"])
     if keep:
@@ -72,14 +75,14 @@ def _block_forward(x, P, cfg, keep):
         g, hpre = ops.gemm_nt(h2, P["w_fc"], P["b_fc"], epi=ops.EPI_ACT, act=act), None
     y = ops.gemm_nt(g, P["w_proj"], P["b_proj"], epi=ops.EPI_ADD, aux=x1)
     if keep:
-        return y, (h1, qkv, a, x1, h2, hpre, g)
+        return y, (h1, qkv, a, stats, x1, h2, hpre, g)
     return y, None
 
 
 def _block_backward(x, dy, box, P, cfg):
     """box: one-element list holding the intermediates tuple (popped so they can be freed early)."""
     B, L, H, causal, act = cfg["B"], cfg["L"], cfg["H"], cfg["causal"], cfg["act"]
-    h1, qkv, a, x1, h2, hpre, g = box.pop()
+    h1, qkv, a, stats, x1, h2, hpre, g = box.pop()
     dy = dy.contiguous()
     # y = x1 + c_proj(g)
     dh = ops.gemm_nt(dy, P["wt_proj"], epi=ops.EPI_DACT, act=act, aux=hpre)     # [M,4D]
@@ -96,8 +99,8 @@ def _block_backward(x, dy, box, P, cfg):
     da = ops.gemm_nt(dx1, P["wt_out"])
     d_w_out = ops.gemm_tn(dx1, a, P["dt_w_out"])
     d_b_out = ops.colsum(dx1)
-    dqkv = ops.attention_bwd(qkv, a, da, B, L, H, causal)
-    del da, a, qkv
+    dqkv = ops.attention_bwd(qkv, a, da, stats, B, L, H, causal)
+    del da, a, qkv, stats
     dh1 = ops.gemm_nt(dqkv, P["wt_in"])
     d_w_in = ops.gemm_tn(dqkv, h1, P["dt_w_in"])
     d_b_in = ops.colsum(dqkv)

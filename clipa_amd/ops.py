@@ -165,22 +165,26 @@ def layernorm_bwd(x, gamma, dy, dres=None, eps=1e-5):
     return dx, dgamma, dbeta
 
 
-def attention_fwd(qkv, B, L, H, causal):
-    """qkv [B*L, 3*H*64] bf16 (q | k | v column blocks) -> out [B*L, H*64] bf16."""
+def attention_fwd(qkv, B, L, H, causal, want_stats=False):
+    """qkv [B*L, 3*H*64] bf16 (q | k | v column blocks) -> out [B*L, H*64] bf16 (+ softmax statistics
+    f32 [B*H*L, 2] for the backward when want_stats)."""
     _chk(qkv, bf16, "qkv", 2)
     D = qkv.shape[1] // 3
     dh = D // H
     out = torch.empty((B * L, D), device=qkv.device, dtype=bf16)
     base = qkv.data_ptr()
     ld = qkv.stride(0)
+    stats = torch.empty((B * H * L, 2), device=qkv.device, dtype=f32) if want_stats else None
     with _Timed("attention_fwd", 4.0 * B * H * L * L * dh * (0.5 if causal else 1.0)):
         lib.call("clipa_attention_fwd", ctypes.c_void_p(base), ctypes.c_void_p(base + 2 * D),
-                 ctypes.c_void_p(base + 4 * D), _p(out), B, H, L, dh, ld, D, 1.0 / math.sqrt(dh), int(causal), _stream())
-    return out
+                 ctypes.c_void_p(base + 4 * D), _p(out), _p(stats), B, H, L, dh, ld, D, 1.0 / math.sqrt(dh), int(causal),
+                 _stream())
+    return (out, stats) if want_stats else out
 
 
-def attention_bwd(qkv, out, dout, B, L, H, causal):
+def attention_bwd(qkv, out, dout, stats, B, L, H, causal):
     _chk(qkv, bf16, "qkv", 2)
+    _chk(stats, f32, "stats", 2)
     _chk(out, bf16, "out", 2)
     _chk(dout, bf16, "dout", 2)
     dout = dout.contiguous()
@@ -190,7 +194,7 @@ def attention_bwd(qkv, out, dout, B, L, H, causal):
     base, dbase = qkv.data_ptr(), dqkv.data_ptr()
     with _Timed("attention_bwd", 10.0 * B * H * L * L * dh * (0.5 if causal else 1.0)):
         lib.call("clipa_attention_bwd", ctypes.c_void_p(base), ctypes.c_void_p(base + 2 * D),
-                 ctypes.c_void_p(base + 4 * D), _p(out), _p(dout), ctypes.c_void_p(dbase), ctypes.c_void_p(dbase + 2 * D),
+                 ctypes.c_void_p(base + 4 * D), _p(out), _p(dout), _p(stats), ctypes.c_void_p(dbase), ctypes.c_void_p(dbase + 2 * D),
                  ctypes.c_void_p(dbase + 4 * D), B, H, L, dh, qkv.stride(0), D, dqkv.stride(0), 1.0 / math.sqrt(dh),
                  int(causal), _stream())
     return dqkv

@@ -67,12 +67,13 @@ int clipa_layernorm_bwd(const void* x, const float* gamma, const void* dy, const
 /* softmax(q.k^T * scale + mask).v per (batch, head); q/k/v are column blocks of the packed projection
  * output (row stride ld_qkv), out is [B*L, H*dh] (row stride ld_o). causal = additive triu(1)*-inf mask.
  * Replaces F.scaled_dot_product_attention inside nn.MultiheadAttention (transformer.py:223-236). */
-int clipa_attention_fwd(const void* q, const void* k, const void* v, void* out, int64_t B, int64_t H,
-                        int64_t L, int64_t dh, int64_t ld_qkv, int64_t ld_o, float scale, int causal,
-                        void* stream);
+/* stats (optional in fwd, required in bwd): f32 [B*H*L][2] = (scale*log2(e)*rowmax, 1/rowsum) of the softmax. */
+int clipa_attention_fwd(const void* q, const void* k, const void* v, void* out, float* stats, int64_t B,
+                        int64_t H, int64_t L, int64_t dh, int64_t ld_qkv, int64_t ld_o, float scale,
+                        int causal, void* stream);
 int clipa_attention_bwd(const void* q, const void* k, const void* v, const void* out, const void* d_out,
-                        void* dq, void* dk, void* dv, int64_t B, int64_t H, int64_t L, int64_t dh,
-                        int64_t ld_qkv, int64_t ld_o, int64_t ld_dqkv, float scale, int causal,
+                        const float* stats, void* dq, void* dk, void* dv, int64_t B, int64_t H, int64_t L,
+                        int64_t dh, int64_t ld_qkv, int64_t ld_o, int64_t ld_dqkv, float scale, int causal,
                         void* stream);
 
 /* image [B,3,S,S] (or NHWC) u8/bf16/f32 -> bf16 patch matrix [B*(S/P)^2, Kp], elements in (ph,pw,c)

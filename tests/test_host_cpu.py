@@ -106,7 +106,7 @@ def test_argument_errors_are_reported_not_thrown():
     handle = lib.load()
     rc = handle.clipa_gemm_nt(None, None, None, None, None, None, 16, 16, 12, 16, 16, 16, 0, 1.0, 0, 0, 0, None)
     assert rc < 0 and "multiple of 8" in lib.last_error()
-    rc = handle.clipa_attention_fwd(None, None, None, None, 1, 1, 10, 80, 240, 80, 1.0, 0, None)
+    rc = handle.clipa_attention_fwd(None, None, None, None, None, 1, 1, 10, 80, 240, 80, 1.0, 0, None)
     assert rc < 0 and "head dim" in lib.last_error()
 
 

@@ -138,9 +138,10 @@ def test_attention(B, H, L, causal):
     x = qkv.double().reshape(B, L, 3 * D).requires_grad_(True)
     o = O.attention(x, H, causal)
     o.backward(dout.double().reshape(B, L, D))
-    got = ops().attention_fwd(qkv.to(DEV), B, L, H, causal)
+    got, stats = ops().attention_fwd(qkv.to(DEV), B, L, H, causal, want_stats=True)
     check("fwd", got.reshape(B, L, D), o, 2 ** -6, 8e-3)
-    dq = ops().attention_bwd(qkv.to(DEV), got, dout.to(DEV), B, L, H, causal)
+    assert torch.equal(got, ops().attention_fwd(qkv.to(DEV), B, L, H, causal))
+    dq = ops().attention_bwd(qkv.to(DEV), got, dout.to(DEV), stats, B, L, H, causal)
     check("dqkv", dq.reshape(B, L, 3 * D), x.grad, 2 ** -5, 2e-2)
 
 

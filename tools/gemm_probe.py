@@ -39,12 +39,12 @@ else:
     B, H, L = a1, a2, a3
     causal = extra == "1"
     qkv = torch.randn(B * L, 3 * 64 * H, device=dev).to(bf16)
-    o = ops.attention_fwd(qkv, B, L, H, causal)
+    o, st = ops.attention_fwd(qkv, B, L, H, causal, want_stats=True)
     do = torch.randn_like(o)
     for _ in range(iters):
         if kind == "attn_fwd":
             ops.attention_fwd(qkv, B, L, H, causal)
         else:
-            ops.attention_bwd(qkv, o, do, B, L, H, causal)
+            ops.attention_bwd(qkv, o, do, st, B, L, H, causal)
 torch.cuda.synchronize()
 print("done")

@@ -75,9 +75,9 @@ def main():
         ms = timeit(lambda: ops.attention_fwd(qkv, B, L, H, causal))
         fl = 4.0 * B * H * L * L * 64 * (0.5 if causal else 1)
         emit(kernel="attention_fwd", tag=tag, B=B, H=H, L=L, ms=round(ms, 3), tflops=round(fl / ms / 1e9, 1))
-        o = ops.attention_fwd(qkv, B, L, H, causal)
+        o, st = ops.attention_fwd(qkv, B, L, H, causal, want_stats=True)
         do = torch.randn_like(o)
-        ms = timeit(lambda: ops.attention_bwd(qkv, o, do, B, L, H, causal))
+        ms = timeit(lambda: ops.attention_bwd(qkv, o, do, st, B, L, H, causal))
         emit(kernel="attention_bwd", tag=tag, B=B, H=H, L=L, ms=round(ms, 3), tflops=round(2.5 * fl / ms / 1e9, 1))
         del qkv, o, do
     for D in (768, 1024):
