@@ -19,6 +19,7 @@
 #include "common.h"
 #include "clipa_hip.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -263,10 +264,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
   const int rowoffB = (wn * 64 + l31) * 128;
   const int nkt = (p.K + BK - 1) / BK;
 
+  // Tile order inside an XCD's range: groups of GM A-panels, N-tile major inside a group, so the ~32
+  // tiles an XCD runs concurrently touch GM A-panels x (32/GM) B-tiles instead of 2 x 16 (fewer distinct
+  // operand tiles per L2).  p.abl bit 3 selects the plain row-major order for A/B experiments.
   auto tile_origin = [&](unsigned t, int& m0, int& n0) {
-    const int tm = (int)(t / (unsigned)tilesN);
-    m0 = tm * BM;
-    n0 = ((int)t - tm * tilesN) * BN;
+    const int GM = (p.abl & 8) ? 1 : 4;
+    const int per = GM * tilesN;
+    const int g = (int)t / per, r = (int)t - g * per;
+    const int gm = min(GM, tilesM - g * GM);
+    const int tn = r / gm, mm = r - tn * gm;
+    m0 = (g * GM + mm) * BM;
+    n0 = tn * BN;
   };
   auto stage = [&](int buf, int m0, int n0, int k0) {
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A + (size_t)m0 * p.lda * 2, (unsigned)(min(BM, p.M - m0) * p.lda * 2));
@@ -459,6 +467,296 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_nt v3: persistent tiles + WAVE ROLES.  vmcnt is per wave and counts stores as well as loads, so a
+// wave that both feeds the DMA ring and writes C must drain its stores before every ring hand-off.  Here
+// waves 0-3 ("loaders") issue every LDS-DMA (operand ring + the aux/residual window) and never store to
+// global memory; waves 4-7 ("storers") issue every global store and never touch the DMA queue.  The
+// loaders' `s_waitcnt vmcnt(0)` then covers DMA only, the storers' C tile drains underneath the next
+// tile's main loop, and all eight waves run the same MFMA main loop.  The DMA is issued from inline asm
+// (hidden from hipcc, which otherwise puts vmcnt(0) in front of every LDS read while a DMA may be pending).
+__device__ __forceinline__ u32x4 make_srd(const void* base, unsigned bytes) {
+  const unsigned long long b = (unsigned long long)base;
+  u32x4 s;
+  s[0] = (unsigned)b;
+  s[1] = (unsigned)(b >> 32) & 0xffffu;   // stride 0
+  s[2] = bytes;
+  s[3] = 0x00020000u;
+  return s;
+}
+__device__ __forceinline__ void dma16(const u32x4 srd, unsigned lds_addr, unsigned voff, unsigned soff) {
+  unsigned keep;
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+               "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+#define WG_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <int EPI, bool SETPRIO>
+__global__ __launch_bounds__(NTHREADS) void gemm_nt3_kernel(NTArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool NEED_AUX = (EPI == CLIPA_EPI_ADD || EPI == CLIPA_EPI_DACT);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wm = wave >> 2, wn = wave & 3;
+  const bool loader = wave < 4;              // wave-uniform role
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  char* cb = smem + CBUF_OFF;
+
+  const int tilesN = (p.N + BN - 1) / BN;
+  const int tilesM = (p.M + BM - 1) / BM;
+  const unsigned ntiles = (unsigned)(tilesM * tilesN);
+  const unsigned G = gridDim.x, xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+  const unsigned gx = (G - xcd + 7u) >> 3;
+  const unsigned q8 = ntiles >> 3, r8 = ntiles & 7u;
+  const unsigned base = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const unsigned len = q8 + (xcd < r8 ? 1u : 0u);
+
+  // loader wave lw moves pieces pc = j*4 + lw (j = 0..7) of each 32-piece operand image; a piece is 8 rows x
+  // 128 B.  The row's chunk swizzle does not depend on j, so one voffset per operand + a scalar offset per j.
+  const int lw = wave & 3;
+  const int row0 = lw * 8 + (lane >> 3);
+  const int chunk0 = (lane & 7) ^ ((row0 >> 1) & 7);
+  const unsigned voffA0 = (unsigned)(row0 * p.lda * 2 + chunk0 * 16);
+  const unsigned voffB0 = (unsigned)(row0 * p.ldb * 2 + chunk0 * 16);
+  const int kel0 = chunk0 * 8;
+  const int sw = (l31 >> 1) & 7;
+  const int rowoffA = (wm * 128 + l31) * 128;
+  const int rowoffB = (wn * 64 + l31) * 128;
+  const int nkt = (p.K + BK - 1) / BK;      // host guarantees nkt >= 3 for this kernel
+
+  auto tile_origin = [&](unsigned t, int& m0, int& n0) {
+    const int GM = 4;
+    const int per = GM * tilesN;
+    const int g = (int)t / per, r = (int)t - g * per;
+    const int gm = min(GM, tilesM - g * GM);
+    const int tn = r / gm, mm = r - tn * gm;
+    m0 = (g * GM + mm) * BM;
+    n0 = tn * BN;
+  };
+  auto stage = [&](int buf, int m0, int n0, int k0) {   // loaders only
+    const u32x4 rsA = make_srd(p.A + (size_t)m0 * p.lda * 2, (unsigned)(min(BM, p.M - m0) * p.lda * 2));
+    const u32x4 rsB = make_srd(p.B + (size_t)n0 * p.ldb * 2, (unsigned)(min(BN, p.N - n0) * p.ldb * 2));
+    const unsigned oob = (k0 + kel0 >= p.K) ? 0x80000000u : 0u;
+    const unsigned sA = lds0 + buf * STAGE_BYTES + lw * 1024, sB = sA + IMG_BYTES;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      dma16(rsA, sA + j * 4096, voffA0 | oob, (unsigned)(k0 * 2 + j * 32 * p.lda * 2));
+      dma16(rsB, sB + j * 4096, voffB0 | oob, (unsigned)(k0 * 2 + j * 32 * p.ldb * 2));
+    }
+  };
+  // aux rows [64*pass, +64) of the tile -> a 32 KiB window, stored with the C window's chunk swizzle
+  // (chunk c of row r lives at chunk position c ^ (r & 31)); 32 pieces of 2 rows, 8 per loader wave
+  auto fetch_aux = [&](int m0, int n0, int pass, unsigned win) {
+    const int rows_left = p.M - (m0 + pass * 64);
+    const int cols_left = p.N - n0;
+    const u32x4 rs = make_srd(p.aux + ((size_t)(m0 + pass * 64) * p.ldaux + n0) * 2,
+                              rows_left > 0 ? (unsigned)((long)min(rows_left, 64) * p.ldaux * 2) : 0u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int pc = j * 4 + lw;
+      const int row = 2 * pc + (lane >> 5);
+      const int c = (lane & 31) ^ (row & 31);                         // source chunk for this LDS position
+      const unsigned oob = (c * 8 >= cols_left) ? 0x80000000u : 0u;
+      dma16(rs, win + pc * 1024, (unsigned)((lane >> 5) * p.ldaux * 2 + c * 16) | oob, (unsigned)(pc * 2 * p.ldaux * 2));
+    }
+  };
+
+  if (idx >= len) return;
+  unsigned it = idx;
+  int m0, n0;
+  tile_origin(base + it, m0, n0);
+  if (loader) stage(0, m0, n0, 0);
+  unsigned gk = 0;
+  for (;;) {
+    const bool has_next = it + gx < len;
+    int m1 = 0, n1 = 0;
+    if (has_next) tile_origin(base + it + gx, m1, n1);
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+
+    for (int kt = 0; kt < nkt; ++kt, ++gk) {
+      if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my DMA pieces of K tile gk have landed
+      WG_BARRIER_LDS();                                               // ... and so have everyone else's
+      if (loader) {
+        if (kt + 1 < nkt) stage((gk + 1) & 1, m0, n0, (kt + 1) * BK);
+        else if (has_next) stage((gk + 1) & 1, m1, n1, 0);
+        // Everything a tile needs besides its operands rides the loaders' DMA queue into the idle C window,
+        // because a storer wave must never wait on a global load while its C stores drain (one vmcnt for
+        // both): kt 0: the 256 bias floats (1 KiB); kt 2: the aux rows of epilogue pass 0.
+        if (kt == 0 && wave == 0 && p.bias) dma16(make_srd(p.bias + n0, (unsigned)((p.N - n0) * 4)), lds0 + CBUF_OFF, (unsigned)(lane * 16), 0u);
+        if (NEED_AUX && kt == 2) fetch_aux(m0, n0, 0, lds0 + CBUF_OFF);
+      }
+      if (kt == 1 && p.bias) {
+        // fold the bias into the fp32 accumulators (out = alpha * (acc + bias / alpha)): no registers held
+        // across the main loop, no global load in the epilogue
+        const float ia = 1.0f / p.alpha;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 b4 = *(const float4*)(cb + (wn * 64 + ni * 32 + 8 * q + 4 * hi) * 4);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+              acc[ni][mi][4 * q + 0] += b4.x * ia;
+              acc[ni][mi][4 * q + 1] += b4.y * ia;
+              acc[ni][mi][4 * q + 2] += b4.z * ia;
+              acc[ni][mi][4 * q + 3] += b4.w * ia;
+            }
+          }
+      }
+      const char* sA = smem + (gk & 1) * STAGE_BYTES;
+      const char* sB = sA + IMG_BYTES;
+      bf16x8 fa[2][4], fb[2][2];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) fa[0][mi] = *(const bf16x8*)(sA + rowoffA + mi * 4096 + ((hi ^ sw) << 4));
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) fb[0][ni] = *(const bf16x8*)(sB + rowoffB + ni * 4096 + ((hi ^ sw) << 4));
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks < 3) {
+          const int coff = ((2 * (ks + 1) + hi) ^ sw) << 4;
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) fa[nxt][mi] = *(const bf16x8*)(sA + rowoffA + mi * 4096 + coff);
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) fb[nxt][ni] = *(const bf16x8*)(sB + rowoffB + ni * 4096 + coff);
+        }
+        if (SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][ni], fa[cur][mi], acc[ni][mi], 0, 0, 0);
+        if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+      }
+    }
+
+    // ---- epilogue: 4 passes of 64 rows.  Phase 1 (the waves that own the rows; ALL epilogue maths, in MFMA
+    // fragment layout): acc -> bf16, activation / residual / activation-backward against the aux fragment read
+    // from LDS -> C window.  Phase 2 (storer waves only): copy window(s) -> global, 16 B per lane, full rows.
+    // Windows: C window (32 KiB, after the ring) + two 32 KiB windows in the ring slot the last K tile was read
+    // from (idle until the next tile's second K tile).  Aux rows: pass 0 in place in the C window (DMA'd during
+    // the main loop), pass 1 -> win0, pass 2 -> win1, pass 3 -> win0; EPI_ACT puts the pre-activation tile of
+    // pass p into win(p & 1).
+    {
+      const int act = p.act;
+      const unsigned win0 = lds0 + ((gk + 1) & 1) * STAGE_BYTES, win1 = win0 + 32768;
+      char* w0p = smem + ((gk + 1) & 1) * STAGE_BYTES;
+      WG_BARRIER_LDS();                        // every wave is done reading the last K tile's ring slot
+      if (NEED_AUX && loader) { fetch_aux(m0, n0, 1, win0); fetch_aux(m0, n0, 2, win1); }
+      auto do_pass = [&](auto PASS) {
+        constexpr int pass = decltype(PASS)::value;
+        if (NEED_AUX && loader) {              // aux rows of this pass have landed (loads retire in order)
+          if (pass == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // younger: aux rows of passes 1, 2
+          if (pass == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // younger: aux rows of pass 2
+          if (pass >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (pass > 0 || NEED_AUX) WG_BARRIER_LDS();   // storers are done with the windows of pass-1 / aux visible
+        if (NEED_AUX && loader && pass == 2) fetch_aux(m0, n0, 3, win0);
+        if (wm == (pass >> 1)) {
+          char* auxp = pass == 0 ? cb : (pass == 2 ? w0p + 32768 : w0p);      // where this pass's aux rows sit
+          char* prep = w0p + (pass & 1) * 32768;                              // EPI_ACT: pre-activation window
+#pragma unroll
+          for (int mi2 = 0; mi2 < 2; ++mi2) {
+            const int mi = 2 * (pass & 1) + mi2;
+            const int row = mi2 * 32 + l31;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int nl = wn * 64 + ni * 32 + 8 * q + 4 * hi;
+                const int off = row * 512 + ((((nl >> 3) ^ row) & 31) << 4) + (nl & 7) * 2;
+                u32x2 w;
+                w[0] = pack2bf(acc[ni][mi][4 * q + 0] * p.alpha, acc[ni][mi][4 * q + 1] * p.alpha);
+                w[1] = pack2bf(acc[ni][mi][4 * q + 2] * p.alpha, acc[ni][mi][4 * q + 3] * p.alpha);
+                if constexpr (EPI != CLIPA_EPI_NONE) {
+                  float v[4] = {__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u),
+                                __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)};
+                  float a[4] = {0.f, 0.f, 0.f, 0.f};
+                  if constexpr (NEED_AUX) {
+                    const u32x2 av = *(const u32x2*)(auxp + off);
+                    a[0] = __uint_as_float(av[0] << 16); a[1] = __uint_as_float(av[0] & 0xffff0000u);
+                    a[2] = __uint_as_float(av[1] << 16); a[3] = __uint_as_float(av[1] & 0xffff0000u);
+                  }
+                  if constexpr (EPI == CLIPA_EPI_ACT) *(u32x2*)(prep + off) = w;
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    if constexpr (EPI == CLIPA_EPI_ADD) v[e] += a[e];
+                    else if constexpr (EPI == CLIPA_EPI_ACT)
+                      v[e] = act == ACT_GELU_ERF ? act_fwd<ACT_GELU_ERF>(v[e]) : (act == ACT_GELU_TANH ? act_fwd<ACT_GELU_TANH>(v[e]) : act_fwd<ACT_QUICK_GELU>(v[e]));
+                    else
+                      v[e] *= act == ACT_GELU_ERF ? act_bwd<ACT_GELU_ERF>(a[e]) : (act == ACT_GELU_TANH ? act_bwd<ACT_GELU_TANH>(a[e]) : act_bwd<ACT_QUICK_GELU>(a[e]));
+                  }
+                  w[0] = pack2bf(v[0], v[1]);
+                  w[1] = pack2bf(v[2], v[3]);
+                }
+                *(u32x2*)(cb + off) = w;
+              }
+          }
+        }
+        WG_BARRIER_LDS();
+        if (!loader) {
+          // storers: 256 threads x 8 chunks = 64 rows x 32 chunks; chunk c = j*256 + t -> row c>>5, column c&31
+          const int t = tid - 256;
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            u32x4 cv[4], xv[4];
+            unsigned a[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int c = (half * 4 + j) * 256 + t;
+              const int row = c >> 5, cc = c & 31;
+              a[j] = row * 512 + (((cc ^ row) & 31) << 4);
+            }
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(cv[0]), "=&v"(cv[1]), "=&v"(cv[2]), "=&v"(cv[3])
+                         : "v"(a[0] + lds0 + CBUF_OFF), "v"(a[1] + lds0 + CBUF_OFF), "v"(a[2] + lds0 + CBUF_OFF), "v"(a[3] + lds0 + CBUF_OFF)
+                         : "memory");
+            if constexpr (EPI == CLIPA_EPI_ACT) {
+              const unsigned pw = win0 + (pass & 1) * 32768;
+              asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\t"
+                           "s_waitcnt lgkmcnt(0)"
+                           : "=&v"(xv[0]), "=&v"(xv[1]), "=&v"(xv[2]), "=&v"(xv[3])
+                           : "v"(a[0] + pw), "v"(a[1] + pw), "v"(a[2] + pw), "v"(a[3] + pw) : "memory");
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int c = (half * 4 + j) * 256 + t;
+              const int row = c >> 5, cc = c & 31;
+              const int m = m0 + pass * 64 + row, n = n0 + cc * 8;
+              if (m < p.M && n < p.N) {
+                if constexpr (EPI == CLIPA_EPI_ACT) {
+                  if (p.C2) *(u32x4*)(p.C2 + ((size_t)m * p.ldc + n) * 2) = xv[j];
+                }
+                *(u32x4*)(p.C + ((size_t)m * p.ldc + n) * 2) = cv[j];
+              }
+            }
+          }
+        }
+      };
+      do_pass(std::integral_constant<int, 0>{});
+      do_pass(std::integral_constant<int, 1>{});
+      do_pass(std::integral_constant<int, 2>{});
+      do_pass(std::integral_constant<int, 3>{});
+    }
+    if (!has_next) break;
+    it += gx;
+    m0 = m1;
+    n0 = n1;
+  }
+}
+#undef WG_BARRIER_LDS
+
+// ------------------------------------------------------------------------------------------------
 struct TNArgs {
   const char* P; const char* Q; float* O;
   int M, R, C;
@@ -607,7 +905,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, void* __res
 
 bool g_attr_done = false;
 int g_num_cu = 256;
-int g_nt_variant = 2;
+int g_nt_variant = 5;
 int g_abl = 0;
 int ensure_attrs() {
   if (g_attr_done) return 0;
@@ -624,16 +922,29 @@ int ensure_attrs() {
     e = hipFuncSetAttribute(v2[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES);
     if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_nt2): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
   }
+  const void* v3[4] = {(const void*)gemm_nt3_kernel<CLIPA_EPI_NONE, true>, (const void*)gemm_nt3_kernel<CLIPA_EPI_ACT, true>,
+                       (const void*)gemm_nt3_kernel<CLIPA_EPI_ADD, true>, (const void*)gemm_nt3_kernel<CLIPA_EPI_DACT, true>};
+  for (int i = 0; i < 4; ++i) {
+    e = hipFuncSetAttribute(v3[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES);
+    if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_nt3): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
+  }
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cu = prop.multiProcessorCount;
-  if (const char* v = getenv("CLIPA_GEMM_NT")) g_nt_variant = atoi(v);
-  if (const char* v = getenv("CLIPA_GEMM_ABL")) g_abl = atoi(v);   // 1 = one tile per workgroup, 2 = persistent, 3 = persistent + setprio
+  if (const char* v = getenv("CLIPA_GEMM_NT")) g_nt_variant = atoi(v);   // 1 = one tile per workgroup, 2 = persistent, 3 = persistent + setprio
+  if (const char* v = getenv("CLIPA_GEMM_ABL")) g_abl = atoi(v);
   g_attr_done = true;
   return 0;
 }
 
 }  // namespace
+
+extern "C" int clipa_debug_set(int gemm_nt_variant, int ablation_flags) {
+  if (int rc = ensure_attrs()) return rc;
+  g_nt_variant = gemm_nt_variant;
+  g_abl = ablation_flags;
+  return CLIPA_OK;
+}
 
 extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, const float* bias,
                              const void* aux, int64_t M, int64_t N, int64_t K, int64_t lda,
@@ -652,9 +963,21 @@ extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, co
   a.alpha = alpha; a.epi = epi; a.act = act; a.abl = g_abl;
   const long tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   hipStream_t st = (hipStream_t)stream;
+  // 5 (default): loader/storer wave roles for plain (bias-only) epilogues - measured +11..15 % on the K = 1024
+  // shapes - while fused-activation / residual epilogues stay on the all-waves epilogue of v2 (their epilogue
+  // maths is VALU-bound and wants all eight waves; measured 10..30 % slower under the role split);
+  // 6: role split for every epilogue (experiments).
+  if (g_nt_variant >= 5 && !out_f32 && K >= 3 * BK && (epi == CLIPA_EPI_NONE || g_nt_variant >= 6)) {
+    const unsigned grid = (unsigned)(tiles < g_num_cu ? tiles : g_num_cu);
+    if (epi == CLIPA_EPI_ACT) hipLaunchKernelGGL((gemm_nt3_kernel<CLIPA_EPI_ACT, true>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
+    else if (epi == CLIPA_EPI_ADD) hipLaunchKernelGGL((gemm_nt3_kernel<CLIPA_EPI_ADD, true>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
+    else if (epi == CLIPA_EPI_DACT) hipLaunchKernelGGL((gemm_nt3_kernel<CLIPA_EPI_DACT, true>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
+    else hipLaunchKernelGGL((gemm_nt3_kernel<CLIPA_EPI_NONE, true>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
+    return clipa_check_launch("gemm_nt3");
+  }
   if (g_nt_variant >= 2) {
     const unsigned grid = (unsigned)(tiles < g_num_cu ? tiles : g_num_cu);
-    const bool prio = g_nt_variant == 3;
+    const bool prio = g_nt_variant == 3 || g_nt_variant == 5;
     if (out_f32 && prio) hipLaunchKernelGGL((gemm_nt2_kernel<true, true>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
     else if (out_f32) hipLaunchKernelGGL((gemm_nt2_kernel<true, false>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
     else if (prio) hipLaunchKernelGGL((gemm_nt2_kernel<false, true>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);

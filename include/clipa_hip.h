@@ -40,6 +40,10 @@ extern "C" {
 
 const char* clipa_last_error(void);
 int clipa_version(void);
+/* kernel-experiment hook (tools/gemm_ab.py): gemm_nt variant 1 = one tile per workgroup, 2 = persistent tiles
+ * (default), 3 = persistent + s_setprio; ablation bit flags (1 no global stores, 2 no epilogue, 4 no bias,
+ * 8 row-major tile order).  Production callers never touch it. */
+int clipa_debug_set(int gemm_nt_variant, int ablation_flags);
 
 /* C[M,N] = epi(alpha * A[M,K] . B[N,K]^T + bias[N]); A,B bf16; C bf16 (or f32 when out_f32, epi NONE).
  * Replaces nn.Linear / packed in-proj / out-proj / conv1-as-GEMM / `@ proj` forward and, with B = W^T,
