@@ -839,9 +839,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TNArgs p) {
     if (mt + 1 < nmt) stage((mt + 1) & 1, (long)(mt + 1) * 64);
     const char* sP = smem + (mt & 1) * STAGE_BYTES;
     const char* sQ = sP + IMG_BYTES;
-#pragma unroll
-    for (int ms = 0; ms < 4; ++ms) {
-      bf16x8 fp[4], fq[2];
+    // fragments of k-step ms+1 are fetched (ds_read_b64_tr_b16) while the MFMAs of step ms issue
+    bf16x8 fp[2][4], fq[2][2];
+    auto load_frags = [&](int ms, bf16x8 (&dp)[4], bf16x8 (&dq)[2]) {
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int row = ms * 16 + 4 * half + rsub;
@@ -851,23 +851,31 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TNArgs p) {
           const int col = wr * 128 + ri * 32 + csub;
           const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (__attribute__((address_space(3))) bf16x4*)(sP + row * 512 + (((col >> 3) ^ swz) << 4) + (col & 7) * 2));
-          fp[ri][4 * half + 0] = v[0]; fp[ri][4 * half + 1] = v[1];
-          fp[ri][4 * half + 2] = v[2]; fp[ri][4 * half + 3] = v[3];
+          dp[ri][4 * half + 0] = v[0]; dp[ri][4 * half + 1] = v[1];
+          dp[ri][4 * half + 2] = v[2]; dp[ri][4 * half + 3] = v[3];
         }
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci) {
           const int col = wc * 64 + ci * 32 + csub;
           const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (__attribute__((address_space(3))) bf16x4*)(sQ + row * 512 + (((col >> 3) ^ swz) << 4) + (col & 7) * 2));
-          fq[ci][4 * half + 0] = v[0]; fq[ci][4 * half + 1] = v[1];
-          fq[ci][4 * half + 2] = v[2]; fq[ci][4 * half + 3] = v[3];
+          dq[ci][4 * half + 0] = v[0]; dq[ci][4 * half + 1] = v[1];
+          dq[ci][4 * half + 2] = v[2]; dq[ci][4 * half + 3] = v[3];
         }
       }
+    };
+    load_frags(0, fp[0], fq[0]);
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms) {
+      const int cur = ms & 1, nxt = cur ^ 1;
+      if (ms < 3) load_frags(ms + 1, fp[nxt], fq[nxt]);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ri = 0; ri < 4; ++ri)
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci)
-          acc[ri][ci] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fp[ri], fq[ci], acc[ri][ci], 0, 0, 0);
+          acc[ri][ci] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fp[cur][ri], fq[cur][ci], acc[ri][ci], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
     }
   }
 
