@@ -582,6 +582,32 @@ extern "C" int clipa_transpose_to_bf16(const void* in, int in_f32, void* out, in
   return clipa_check_launch("transpose_to_bf16");
 }
 
+// out = act(in), bf16 -> bf16 (re-materialises the MLP activation from the stored pre-activation in the
+// backward of a block whose GEMM outputs were kept; transformer.py:218 / model.py:128-129)
+namespace {
+template <int ACT>
+__global__ void activation_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out, long n8) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float f[8];
+    unpack8(*(const u32x4*)(in + i * 8), f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = act_fwd<ACT>(f[k]);
+    *(u32x4*)(out + i * 8) = pack8(f);
+  }
+}
+}  // namespace
+extern "C" int clipa_activation_fwd(const void* in, void* out, int64_t n, int act, void* stream) {
+  if (n % 8 != 0) { clipa_set_error("activation_fwd: n must be a multiple of 8"); return CLIPA_ERR_ARG; }
+  if (n <= 0) return CLIPA_OK;
+  const unsigned grid = grid_for(n / 8);
+  hipStream_t st = (hipStream_t)stream;
+  if (act == ACT_GELU_ERF) hipLaunchKernelGGL(activation_kernel<ACT_GELU_ERF>, dim3(grid), dim3(256), 0, st, (const unsigned short*)in, (unsigned short*)out, (long)(n / 8));
+  else if (act == ACT_GELU_TANH) hipLaunchKernelGGL(activation_kernel<ACT_GELU_TANH>, dim3(grid), dim3(256), 0, st, (const unsigned short*)in, (unsigned short*)out, (long)(n / 8));
+  else if (act == ACT_QUICK_GELU) hipLaunchKernelGGL(activation_kernel<ACT_QUICK_GELU>, dim3(grid), dim3(256), 0, st, (const unsigned short*)in, (unsigned short*)out, (long)(n / 8));
+  else { clipa_set_error("activation_fwd: unknown activation %d", act); return CLIPA_ERR_ARG; }
+  return clipa_check_launch("activation_fwd");
+}
+
 extern "C" int clipa_ce_rows(const float* logits, int64_t rows, int64_t N, int64_t ld, int64_t label0, float gscale,
                              void* dlogits_bf16, int64_t ldd, float* loss_rows, float* dscale_rows, void* stream) {
   if (N % 4 != 0 || ld % 4 != 0 || (dlogits_bf16 && ldd % 4 != 0)) { clipa_set_error("ce_rows: N, ld, ldd must be multiples of 4"); return CLIPA_ERR_ARG; }

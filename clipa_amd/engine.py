@@ -59,7 +59,9 @@ def _like_param(g, p):
 
 # ---------------------------------------------------------------------------------------------
 def _block_forward(x, P, cfg, keep):
-    """x [M,D] bf16. P: dict of operand tensors. Returns y and (if keep) the intermediates."""
+    """x [M,D] bf16. P: dict of operand tensors. Returns y and (if keep) the intermediates.
+    keep: False (nothing), True / "full" (everything the backward reads) or "light" (only the GEMM / attention
+    outputs qkv, a, stats, x1, hpre - LayerNorm outputs and the activation are re-materialised in backward)."""
     B, L, H, causal, act = cfg["B"], cfg["L"], cfg["H"], cfg["causal"], cfg["act"]
     h1 = ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"])
     qkv = ops.gemm_nt(h1, P["w_in"], P["b_in"])
@@ -74,6 +76,8 @@ def _block_forward(x, P, cfg, keep):
     else:
         g, hpre = ops.gemm_nt(h2, P["w_fc"], P["b_fc"], epi=ops.EPI_ACT, act=act), None
     y = ops.gemm_nt(g, P["w_proj"], P["b_proj"], epi=ops.EPI_ADD, aux=x1)
+    if keep == "light":
+        return y, (None, qkv, a, stats, x1, None, hpre, None)
     if keep:
         return y, (h1, qkv, a, stats, x1, h2, hpre, g)
     return y, None
@@ -84,6 +88,9 @@ def _block_backward(x, dy, box, P, cfg):
     B, L, H, causal, act = cfg["B"], cfg["L"], cfg["H"], cfg["causal"], cfg["act"]
     h1, qkv, a, stats, x1, h2, hpre, g = box.pop()
     dy = dy.contiguous()
+    if g is None:        # "light" block: cheap HBM-bound re-materialisation instead of 4 GEMMs + attention
+        g = ops.activation_fwd(hpre, act)
+        h2 = ops.layernorm_fwd(x1, P["ln2_w"], P["ln2_b"], cfg["eps"])
     # y = x1 + c_proj(g)
     dh = ops.gemm_nt(dy, P["wt_proj"], epi=ops.EPI_DACT, act=act, aux=hpre)     # [M,4D]
     d_w_proj = ops.gemm_tn(dy, g, P["dt_w_proj"])
@@ -102,6 +109,8 @@ def _block_backward(x, dy, box, P, cfg):
     dqkv = ops.attention_bwd(qkv, a, da, stats, B, L, H, causal)
     del da, a, qkv, stats
     dh1 = ops.gemm_nt(dqkv, P["wt_in"])
+    if h1 is None:
+        h1 = ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"])
     d_w_in = ops.gemm_tn(dqkv, h1, P["dt_w_in"])
     d_b_in = ops.colsum(dqkv)
     del dqkv, h1
@@ -132,7 +141,9 @@ class ResBlockFn(torch.autograd.Function):
     def forward(ctx, x, cfg, cache, *params):
         P = _block_operands(params, cache)
         needs_grad = any(ctx.needs_input_grad)
-        keep = needs_grad and not cfg["recompute"]
+        keep = False
+        if needs_grad:
+            keep = cfg.get("keep", "light") if (not cfg["recompute"] or cfg.get("keep_this", False)) else False
         y, inter = _block_forward(x, P, cfg, keep)
         ctx.cfg, ctx.cache, ctx.params = cfg, cache, params
         if needs_grad:

@@ -142,17 +142,26 @@ class Transformer(nn.Module):
             _unsupported(f"head dim {width // heads if heads else '?'} (the fused attention kernel covers 64)")
         self.width, self.layers, self.heads, self.act = width, layers, heads, act
         self.grad_checkpointing = False
+        # MI355X engine knob (no reference counterpart): with grad checkpointing on, the first `keep_blocks`
+        # blocks still keep their GEMM / attention outputs ("light" keep, ~18*D bytes per token) so their
+        # backward skips the recompute; 288 GB of HBM usually has room for several blocks' worth.
+        self.keep_blocks = 0
         self.resblocks = nn.ModuleList([_ResBlockParams(width, heads, mlp_ratio) for _ in range(layers)])
 
     def get_cast_dtype(self):
         return self.resblocks[0].mlp.c_fc.weight.dtype
 
     def run(self, x, B, L, causal, cache):
-        cfg = {"B": B, "L": L, "H": self.heads, "causal": bool(causal), "act": self.act, "eps": 1e-5,
-               "recompute": bool(self.grad_checkpointing)}
-        for blk in self.resblocks:
-            x = engine.ResBlockFn.apply(x, cfg, cache, *blk.param_tuple())
+        base = {"B": B, "L": L, "H": self.heads, "causal": bool(causal), "act": self.act, "eps": 1e-5,
+                "recompute": bool(self.grad_checkpointing), "keep": "light"}
+        kept = dict(base, keep_this=True)
+        for i, blk in enumerate(self.resblocks):
+            x = engine.ResBlockFn.apply(x, kept if i < self.keep_blocks else base, cache, *blk.param_tuple())
         return x
+
+    def light_keep_bytes(self, tokens):
+        """HBM bytes one kept block holds between forward and backward for `tokens` rows."""
+        return tokens * 9 * self.width * 2 + tokens * self.heads * 8   # qkv, a, x1, hpre (bf16) + softmax stats
 
 
 class VisionTransformer(nn.Module):

@@ -343,6 +343,15 @@ def transpose_bf16(t):
     return out
 
 
+def activation_fwd(x, act):
+    """bf16 act(x) (gelu erf / tanh / quick)."""
+    _chk(x, bf16, "x")
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    lib.call("clipa_activation_fwd", _p(x), _p(out), x.numel(), act, _stream())
+    return out
+
+
 def ce_rows(logits, label0, gscale, want_grad=True):
     """Row-wise CE with labels label0 + row. Returns loss_rows f32 [R], dlogits bf16 [R,N] | None, dscale_rows."""
     _chk(logits, f32, "logits", 2)

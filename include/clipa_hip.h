@@ -115,6 +115,8 @@ int clipa_cast_to_bf16(const void* in, int in_f32, void* out, int64_t n, void* s
 int clipa_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);
 int clipa_transpose_to_bf16(const void* in, int in_f32, void* out, int64_t R, int64_t C, int64_t ldi,
                             int64_t ldo, void* stream);
+/* out = act(in) elementwise, bf16 (MLP activation re-materialised from the kept pre-activation) */
+int clipa_activation_fwd(const void* in, void* out, int64_t n, int act, void* stream);
 /* F.cross_entropy(logits, arange + label0) rows (loss.py:115-126,152-155): per-row loss, bf16 gradient
  * gscale*(softmax - onehot) and per-row sum_j dlogits_j*logits_j (for d/d logit_scale). */
 int clipa_ce_rows(const float* logits, int64_t rows, int64_t N, int64_t ld, int64_t label0, float gscale,

@@ -163,6 +163,10 @@ def transpose_bf16(t):
     return t.to(bf16).T.contiguous()
 
 
+def activation_fwd(x, act):
+    return _act(x.float(), act).to(bf16)
+
+
 def ce_rows(logits, label0, gscale, want_grad=True):
     R, N = logits.shape
     labels = torch.arange(R) + label0
