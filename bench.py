@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "amp_bf16"],
                     help="bf16 = reference 'bf16' mode (bf16 weights); amp_bf16 = fp32 master weights")
     ap.add_argument("--keep-blocks", default="auto", help="'auto' or 'NV,NT': blocks per tower that skip recompute")
+    ap.add_argument("--keep-fraction", type=float, default=0.88, help="share of the free HBM 'auto' may spend")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="pairs per CPU-baseline step")
     ap.add_argument("--cpu-timeout", type=int, default=240)
@@ -184,7 +185,7 @@ def main():
         step()                                   # one extra untimed all-recompute step, only to measure its peak
         torch.cuda.synchronize()
         peak = torch.cuda.max_memory_allocated(dev)
-        budget = int(0.85 * (total_mem - peak)) - (8 << 30)
+        budget = int(args.keep_fraction * (total_mem - peak)) - (6 << 30)
         keep_v = max(0, min(cfg["vision_cfg"]["layers"], budget // per_v))
         keep_t = max(0, min(cfg["text_cfg"]["layers"], (budget - keep_v * per_v) // per_t))
     else:

@@ -546,6 +546,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt3_kernel(NTArgs p) {
       dma16(rsB, sB + j * 4096, voffB0 | oob, (unsigned)(k0 * 2 + j * 32 * p.ldb * 2));
     }
   };
+  auto stage_part = [&](int buf, int m0, int n0, int k0, int part) {   // a quarter of stage(): pieces j = 2*part, 2*part+1
+    const u32x4 rsA = make_srd(p.A + (size_t)m0 * p.lda * 2, (unsigned)(min(BM, p.M - m0) * p.lda * 2));
+    const u32x4 rsB = make_srd(p.B + (size_t)n0 * p.ldb * 2, (unsigned)(min(BN, p.N - n0) * p.ldb * 2));
+    const unsigned oob = (k0 + kel0 >= p.K) ? 0x80000000u : 0u;
+    const unsigned sA = lds0 + buf * STAGE_BYTES + lw * 1024, sB = sA + IMG_BYTES;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = 2 * part + jj;
+      dma16(rsA, sA + j * 4096, voffA0 | oob, (unsigned)(k0 * 2 + j * 32 * p.lda * 2));
+      dma16(rsB, sB + j * 4096, voffB0 | oob, (unsigned)(k0 * 2 + j * 32 * p.ldb * 2));
+    }
+  };
   // aux rows [64*pass, +64) of the tile -> a 32 KiB window, stored with the C window's chunk swizzle
   // (chunk c of row r lives at chunk position c ^ (r & 31)); 32 pieces of 2 rows, 8 per loader wave
   auto fetch_aux = [&](int m0, int n0, int pass, unsigned win) {
@@ -585,9 +597,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt3_kernel(NTArgs p) {
     for (int kt = 0; kt < nkt; ++kt, ++gk) {
       if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my DMA pieces of K tile gk have landed
       WG_BARRIER_LDS();                                               // ... and so have everyone else's
+      // where the next K tile comes from (this tile, or the first K tile of the next output tile)
+      const bool pf = (kt + 1 < nkt) || has_next;
+      const int pm = (kt + 1 < nkt) ? m0 : m1, pn = (kt + 1 < nkt) ? n0 : n1, pk = (kt + 1 < nkt) ? (kt + 1) * BK : 0;
+      const bool spread = (p.abl & 16) != 0;   // issue the DMA pieces between the MFMA groups instead of up front
       if (loader) {
-        if (kt + 1 < nkt) stage((gk + 1) & 1, m0, n0, (kt + 1) * BK);
-        else if (has_next) stage((gk + 1) & 1, m1, n1, 0);
+        if (pf && !spread) stage((gk + 1) & 1, pm, pn, pk);
         // Everything a tile needs besides its operands rides the loaders' DMA queue into the idle C window,
         // because a storer wave must never wait on a global load while its C stores drain (one vmcnt for
         // both): kt 0: the 256 bias floats (1 KiB); kt 2: the aux rows of epilogue pass 0.
@@ -629,6 +644,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt3_kernel(NTArgs p) {
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) fb[nxt][ni] = *(const bf16x8*)(sB + rowoffB + ni * 4096 + coff);
         }
+        if (loader && pf && spread) stage_part((gk + 1) & 1, pm, pn, pk, ks);
         if (SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
@@ -762,6 +778,7 @@ struct TNArgs {
   int M, R, C;
   long ldp, ldq, ldo;
   int slice_rows;   // multiple of 64
+  float* colsum;    // optional [S][R] partial column sums of P (the bias gradient rides the weight-gradient GEMM)
 };
 
 // LDS image [64 m][256 cols] bf16 (512-B rows, 32 chunks); chunk permutation per row:
@@ -831,6 +848,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TNArgs p) {
   const int rsub = 8 * hi + (i16 >> 2);          // + ms*16 + 4*half
   const int csub = 16 * q16 + 4 * (i16 & 3);     // + colbase (multiple of 32)
 
+  const bool do_colsum = p.colsum != nullptr && tc == 0;   // one C-tile column of workgroups owns the sums
+  const int cs_ch = tid & 31, cs_rg = tid >> 5;             // 32 column chunks x 16 row groups
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int nmt = (int)((mend - mbeg + 63) / 64);
   if (nmt > 0) stage(0, 0);
   for (int mt = 0; mt < nmt; ++mt) {
@@ -839,6 +859,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TNArgs p) {
     if (mt + 1 < nmt) stage((mt + 1) & 1, (long)(mt + 1) * 64);
     const char* sP = smem + (mt & 1) * STAGE_BYTES;
     const char* sQ = sP + IMG_BYTES;
+    if (do_colsum) {
+      // column sums of the P tile (64 m-rows x 256 columns): thread = (16-B column chunk, group of 4 rows)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int row = cs_rg * 4 + rr;
+        float f[8];
+        unpack8(*(const u32x4*)(sP + row * 512 + ((cs_ch ^ tn_swz(row)) << 4)), f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) csum[i] += f[i];
+      }
+    }
     // fragments of k-step ms+1 are fetched (ds_read_b64_tr_b16) while the MFMAs of step ms issue
     bf16x8 fp[2][4], fq[2][2];
     auto load_frags = [&](int ms, bf16x8 (&dp)[4], bf16x8 (&dq)[2]) {
@@ -891,6 +922,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TNArgs p) {
         if (r < p.R && c < p.C) O[(size_t)r * p.ldo + c] = acc[ri][ci][reg];
       }
     }
+  if (do_colsum) {
+    __syncthreads();                       // every wave is done with the ring: reuse it as [16][256] floats
+    float* red = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[cs_rg * 256 + cs_ch * 8 + i] = csum[i];
+    __syncthreads();
+    if (tid < 256) {
+      float a = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) a += red[g * 256 + tid];
+      if (r0 + tid < p.R) p.colsum[(size_t)slice * p.R + r0 + tid] = a;
+    }
+  }
 }
 
 // out[i] = cast(sum_s slab[s][i]); out dtype bf16 or f32
@@ -1006,11 +1050,11 @@ extern "C" int64_t clipa_gemm_tn_workspace(int64_t M, int64_t R, int64_t C, int6
   if (S < 1) S = 1;
   if (mt > 0) { const long per = (mt + S - 1) / S; S = (mt + per - 1) / per; }
   if (nslices) *nslices = S;
-  return S * R * C * (int64_t)sizeof(float);
+  return (S * R * C + S * R) * (int64_t)sizeof(float);   // split-M slabs + partial column sums
 }
 
-extern "C" int clipa_gemm_tn(const void* P, const void* Q, void* out, int64_t M, int64_t R, int64_t C,
-                             int64_t ldp, int64_t ldq, int out_bf16, void* workspace,
+extern "C" int clipa_gemm_tn(const void* P, const void* Q, void* out, float* colsum_out, int64_t M, int64_t R,
+                             int64_t C, int64_t ldp, int64_t ldq, int out_bf16, void* workspace,
                              int64_t workspace_bytes, void* stream) {
   if (R <= 0 || C <= 0) return CLIPA_OK;
   if (R % 8 != 0 || C % 8 != 0 || ldp % 8 != 0 || ldq % 8 != 0) { clipa_set_error("gemm_tn: R, C, ldp, ldq must be multiples of 8"); return CLIPA_ERR_ARG; }
@@ -1024,6 +1068,7 @@ extern "C" int clipa_gemm_tn(const void* P, const void* Q, void* out, int64_t M,
   TNArgs a;
   a.P = (const char*)P; a.Q = (const char*)Q; a.O = (float*)workspace;
   a.M = (int)M; a.R = (int)R; a.C = (int)C; a.ldp = ldp; a.ldq = ldq; a.ldo = C; a.slice_rows = (int)slice_rows;
+  a.colsum = colsum_out ? (float*)workspace + S * R * C : nullptr;
   const long tiles = ((R + 255) / 256) * ((C + 255) / 256);
   hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)tiles, (unsigned)S), dim3(NTHREADS), 2 * STAGE_BYTES, (hipStream_t)stream, a);
   if (int rc = clipa_check_launch("gemm_tn")) return rc;
@@ -1031,5 +1076,7 @@ extern "C" int clipa_gemm_tn(const void* P, const void* Q, void* out, int64_t M,
   const unsigned blocks = (unsigned)((n / 4 + 255) / 256);
   if (out_bf16) hipLaunchKernelGGL(reduce_slabs_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, out, n, (int)S);
   else hipLaunchKernelGGL(reduce_slabs_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, out, n, (int)S);
+  if (colsum_out)   // bias gradient: sum the per-slice partial column sums of P
+    hipLaunchKernelGGL(reduce_slabs_kernel<false>, dim3((unsigned)((R / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)a.colsum, (void*)colsum_out, (long)R, (int)S);
   return clipa_check_launch("gemm_tn_reduce");
 }

@@ -93,26 +93,22 @@ def _block_backward(x, dy, box, P, cfg):
         h2 = ops.layernorm_fwd(x1, P["ln2_w"], P["ln2_b"], cfg["eps"])
     # y = x1 + c_proj(g)
     dh = ops.gemm_nt(dy, P["wt_proj"], epi=ops.EPI_DACT, act=act, aux=hpre)     # [M,4D]
-    d_w_proj = ops.gemm_tn(dy, g, P["dt_w_proj"])
-    d_b_proj = ops.colsum(dy)
+    d_w_proj, d_b_proj = ops.gemm_tn(dy, g, P["dt_w_proj"], want_colsum=True)
     del g, hpre
     dh2 = ops.gemm_nt(dh, P["wt_fc"])                                           # [M,D]
-    d_w_fc = ops.gemm_tn(dh, h2, P["dt_w_fc"])
-    d_b_fc = ops.colsum(dh)
+    d_w_fc, d_b_fc = ops.gemm_tn(dh, h2, P["dt_w_fc"], want_colsum=True)
     del dh, h2
     dx1, d_ln2_w, d_ln2_b = ops.layernorm_bwd(x1, P["ln2_w"], dh2, dres=dy, eps=cfg["eps"])
     del dh2, x1
     # x1 = x + out_proj(a)
     da = ops.gemm_nt(dx1, P["wt_out"])
-    d_w_out = ops.gemm_tn(dx1, a, P["dt_w_out"])
-    d_b_out = ops.colsum(dx1)
+    d_w_out, d_b_out = ops.gemm_tn(dx1, a, P["dt_w_out"], want_colsum=True)
     dqkv = ops.attention_bwd(qkv, a, da, stats, B, L, H, causal)
     del da, a, qkv, stats
     dh1 = ops.gemm_nt(dqkv, P["wt_in"])
     if h1 is None:
         h1 = ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"])
-    d_w_in = ops.gemm_tn(dqkv, h1, P["dt_w_in"])
-    d_b_in = ops.colsum(dqkv)
+    d_w_in, d_b_in = ops.gemm_tn(dqkv, h1, P["dt_w_in"], want_colsum=True)
     del dqkv, h1
     dx, d_ln1_w, d_ln1_b = ops.layernorm_bwd(x, P["ln1_w"], dh1, dres=dx1, eps=cfg["eps"])
     return dx, (d_ln1_w, d_ln1_b, d_w_in, d_b_in, d_w_out, d_b_out, d_ln2_w, d_ln2_b, d_w_fc, d_b_fc, d_w_proj,

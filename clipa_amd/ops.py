@@ -112,8 +112,8 @@ def gemm_nt(a, b, bias=None, *, epi=EPI_NONE, act=ACT_GELU_ERF, aux=None, alpha=
     return (out, pre) if want_pre else out
 
 
-def gemm_tn(p, q, out_dtype=f32):
-    """out[R,C] = p[M,R]^T @ q[M,C]; p, q bf16."""
+def gemm_tn(p, q, out_dtype=f32, want_colsum=False):
+    """out[R,C] = p[M,R]^T @ q[M,C]; p, q bf16.  want_colsum: also return sum_m p[m,:] (f32 [R])."""
     _chk(p, bf16, "p", 2)
     _chk(q, bf16, "q", 2)
     p, ldp = _rowmajor(p)
@@ -126,10 +126,11 @@ def gemm_tn(p, q, out_dtype=f32):
     wsb = lib.query("clipa_gemm_tn_workspace", M, R, C, ctypes.byref(ns))
     ws = torch.empty(max(wsb, 4) // 4, device=p.device, dtype=f32)
     out = torch.empty((R, C), device=p.device, dtype=out_dtype)
+    cs = torch.empty(R, device=p.device, dtype=f32) if want_colsum else None
     with _Timed("gemm_tn", 2.0 * M * R * C):
-        lib.call("clipa_gemm_tn", _p(p), _p(q), _p(out), M, R, C, ldp, ldq, 1 if out_dtype == bf16 else 0, _p(ws),
+        lib.call("clipa_gemm_tn", _p(p), _p(q), _p(out), _p(cs), M, R, C, ldp, ldq, 1 if out_dtype == bf16 else 0, _p(ws),
                  wsb, _stream())
-    return out
+    return (out, cs) if want_colsum else out
 
 
 def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=None):

@@ -56,8 +56,9 @@ int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, const float* 
 /* out[R,C] = sum_m P[m,R] * Q[m,C]  (weight gradients dW = dY^T . X of the same layers; also the
  * gathered-feature gradients of loss.py:135-139).  out is f32 or bf16. workspace: split-M partial slabs. */
 int64_t clipa_gemm_tn_workspace(int64_t M, int64_t R, int64_t C, int64_t* nslices);
-int clipa_gemm_tn(const void* P, const void* Q, void* out, int64_t M, int64_t R, int64_t C, int64_t ldp,
-                  int64_t ldq, int out_bf16, void* workspace, int64_t workspace_bytes, void* stream);
+/* colsum_out (optional, f32 [R]): column sums of P = the bias gradient of the same layer, fused into the pass. */
+int clipa_gemm_tn(const void* P, const void* Q, void* out, float* colsum_out, int64_t M, int64_t R, int64_t C,
+                  int64_t ldp, int64_t ldq, int out_bf16, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* F.layer_norm over the last dim, eps inside sqrt, affine (transformer.py:19-34). x/dx share a dtype
  * (x_f32), y/dy share a dtype (y_f32). bwd: dx = LN'(dy) [+ dres]; dgamma, dbeta f32 [D]. */

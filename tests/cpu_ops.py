@@ -43,8 +43,9 @@ def gemm_nt(a, b, bias=None, *, epi=EPI_NONE, act=0, aux=None, alpha=1.0, out_f3
     return (v, pre) if want_pre else v
 
 
-def gemm_tn(p, q, out_dtype=f32):
-    return (p.float().T @ q.float()).to(out_dtype)
+def gemm_tn(p, q, out_dtype=f32, want_colsum=False):
+    out = (p.float().T @ q.float()).to(out_dtype)
+    return (out, p.float().sum(0)) if want_colsum else out
 
 
 def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=None):

@@ -92,8 +92,9 @@ def test_gemm_tn(M, R, C):
     ref = p.double().T @ q.double()
     out = ops().gemm_tn(p.to(DEV), q.to(DEV), f32)
     check("f32", out, ref, 1e-4, 3e-4 * math.sqrt(M))
-    out = ops().gemm_tn(p.to(DEV), q.to(DEV), bf16)
+    out, cs = ops().gemm_tn(p.to(DEV), q.to(DEV), bf16, want_colsum=True)
     check("bf16", out, ref, 2 ** -7, 3e-4 * math.sqrt(M))
+    check("fused column sums", cs, p.double().sum(0), 1e-5, 1e-4 * math.sqrt(M))
 
 
 def test_gemm_tn_strided_and_many_slices():
