@@ -214,7 +214,7 @@ def main():
         ms = 1e3 * elapsed / args.steps
         pairs_s = B * world * args.steps / elapsed
         gf = train_gflop_per_pair(cfg, args.image_size, args.ctx)
-        nt = prof.get("gemm_nt", {"launches": 0, "ms": 0.0, "work": 0.0})
+        nt = prof.get("gemm_nt", {"launches": 0, "ms": 0.0, "work": 0.0, "bytes": 0.0})
         achieved = nt["work"] / (nt["ms"] * 1e-3) / 1e12 if nt["ms"] > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -236,7 +236,8 @@ def main():
             "loss": round(last_loss, 4), "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA 32x32x16)", "achieved": round(achieved, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                         "traffic": traffic, "launches": nt["launches"],
+                         "traffic": traffic, "algorithmic_bytes_per_launch": round(nt.get("bytes", 0.0) / max(nt["launches"], 1)),
+                         "launches": nt["launches"],
                          "avg_launch_ms": round(nt["ms"] / max(nt["launches"], 1), 4)},
             "kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 2),
                             "tflops": round(v["work"] / max(v["ms"], 1e-9) / 1e9, 1)} for k, v in prof.items()},

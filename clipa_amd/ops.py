@@ -39,16 +39,16 @@ def profile_stop():
     torch.cuda.synchronize()
     out = {}
     for name, recs in prof.items():
-        out[name] = {"launches": len(recs), "ms": sum(a.elapsed_time(b) for a, b, _ in recs),
-                     "work": float(sum(w for _, _, w in recs))}
+        out[name] = {"launches": len(recs), "ms": sum(r[0].elapsed_time(r[1]) for r in recs),
+                     "work": float(sum(r[2] for r in recs)), "bytes": float(sum(r[3] for r in recs))}
     return out
 
 
 class _Timed:
-    __slots__ = ("name", "work", "a")
+    __slots__ = ("name", "work", "nbytes", "a")
 
-    def __init__(self, name, work):
-        self.name, self.work = name, work
+    def __init__(self, name, work, nbytes=0.0):
+        self.name, self.work, self.nbytes = name, work, nbytes
 
     def __enter__(self):
         if _PROF is not None:
@@ -59,7 +59,7 @@ class _Timed:
         if _PROF is not None:
             b = torch.cuda.Event(enable_timing=True)
             b.record()
-            _PROF.setdefault(self.name, []).append((self.a, b, self.work))
+            _PROF.setdefault(self.name, []).append((self.a, b, self.work, self.nbytes))
         return False
 
 
@@ -106,7 +106,9 @@ def gemm_nt(a, b, bias=None, *, epi=EPI_NONE, act=ACT_GELU_ERF, aux=None, alpha=
     if aux is not None:
         _chk(aux, bf16, "aux", 2)
         aux, ldaux = _rowmajor(aux)
-    with _Timed("gemm_nt", 2.0 * M * N * K):
+    osz = 4 if out_f32 else 2
+    nbytes = 2.0 * (M * K + N * K) + osz * M * N + (2.0 * M * N if aux is not None else 0) + (2.0 * M * N if want_pre else 0)
+    with _Timed("gemm_nt", 2.0 * M * N * K, nbytes):
         lib.call("clipa_gemm_nt", _p(a), _p(b), _p(out), _p(pre), _p(bias), _p(aux), M, N, K, lda, ldb, ldc, ldaux,
                  float(alpha), epi, act, 1 if out_f32 else 0, _stream())
     return (out, pre) if want_pre else out
@@ -127,7 +129,7 @@ def gemm_tn(p, q, out_dtype=f32, want_colsum=False):
     ws = torch.empty(max(wsb, 4) // 4, device=p.device, dtype=f32)
     out = torch.empty((R, C), device=p.device, dtype=out_dtype)
     cs = torch.empty(R, device=p.device, dtype=f32) if want_colsum else None
-    with _Timed("gemm_tn", 2.0 * M * R * C):
+    with _Timed("gemm_tn", 2.0 * M * R * C, 2.0 * M * (R + C) + out.element_size() * R * C):
         lib.call("clipa_gemm_tn", _p(p), _p(q), _p(out), _p(cs), M, R, C, ldp, ldq, 1 if out_dtype == bf16 else 0, _p(ws),
                  wsb, _stream())
     return (out, cs) if want_colsum else out

@@ -36,6 +36,15 @@ for s in $STAGES; do
            python "$R/tools/gemm_probe.py" nt 65536 4096 1024 bias 3 > "$R/gpurun_out/pmc/$tag.log" 2>&1)
       done
       python tools/pmc_summary.py gpurun_out/pmc > gpurun_out/pmc_summary.txt 2>&1 ;;
+    pmcbench)
+      # HBM-side traffic counters over the real bench workload (separate passes, counters only)
+      mkdir -p gpurun_out/pmcbench
+      R="$PWD"
+      for set in "FETCH_SIZE" "WRITE_SIZE"; do
+        (cd /tmp && timeout 600 rocprofv3 --pmc $set -d "$R/gpurun_out/pmcbench/$set" -o pmc -- \
+           python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --keep-blocks 12,0 > "$R/gpurun_out/pmcbench/$set.log" 2>&1)
+      done
+      python tools/pmc_summary.py gpurun_out/pmcbench gemm attn > gpurun_out/pmcbench_summary.txt 2>&1 ;;
     prof)
       mkdir -p gpurun_out/prof
       (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o r01 -- \
