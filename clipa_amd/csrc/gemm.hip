@@ -229,7 +229,35 @@ __device__ __forceinline__ u32x4 epi_chunk(int epi, u32x4 v, u32x4 av) {
   return pack8(f);
 }
 
-template <bool OUT_F32, bool SETPRIO>
+// A buffer descriptor as four SGPR words + an LDS-DMA load issued from inline asm: hipcc does not see the
+// load, so it does not put `s_waitcnt vmcnt(0)` in front of LDS reads; the kernel waits by hand (counted vmcnt).
+__device__ __forceinline__ u32x4 make_srd(const void* base, unsigned bytes) {
+  const unsigned long long b = (unsigned long long)base;
+  u32x4 s;
+  s[0] = (unsigned)b;
+  s[1] = (unsigned)(b >> 32) & 0xffffu;   // stride 0
+  s[2] = bytes;
+  s[3] = 0x00020000u;
+  return s;
+}
+__device__ __forceinline__ void dma16(const u32x4 srd, unsigned lds_addr, unsigned voff, unsigned soff) {
+  unsigned keep;
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+               "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+#define WG_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// STAG = true selects the STAGGERED main loop ("nt4"): K is walked in phases of 32 through a ring of four
+// 32 KiB half-slots (A [256][32] + B [256][32] images, 64-byte rows, chunk ^= (row>>2)&3), three phases in
+// flight (96 KiB instead of 64 KiB: the loop is latency x bandwidth bound on the L2->LDS path), waits are
+// counted (`vmcnt(8)`: the two newest phases may still be in flight).  The two wave groups (wm = 0 / 1 = the
+// two waves of every SIMD) are offset by one k-step: group 1 carries the fragments of a phase's second k-step
+// across the barrier, so right after every barrier each SIMD has eight MFMAs to issue while the LDS reads of
+// the new phase are still in flight.
+constexpr int HS_BYTES = 32768;
+
+template <bool OUT_F32, bool SETPRIO, bool STAG = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -290,12 +318,39 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
     }
   };
 
+  // ---- staggered variant: per-wave DMA pieces of a phase.  A piece = 16 rows x 64 B; wave w moves pieces
+  // w and w+8 of the A image and of the B image (4 DMA instructions per wave per phase).
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int chunk4 = (lane & 3) ^ ((lane >> 4) & 3);        // source chunk: (row>>2)&3 == (lane>>4)&3 for every piece
+  const int row4 = wave * 16 + (lane >> 2);
+  const unsigned voff4A0 = (unsigned)(row4 * p.lda * 2 + chunk4 * 16), voff4A1 = voff4A0 + (unsigned)(128 * p.lda * 2);
+  const unsigned voff4B0 = (unsigned)(row4 * p.ldb * 2 + chunk4 * 16), voff4B1 = voff4B0 + (unsigned)(128 * p.ldb * 2);
+  const int sw4 = (l31 >> 2) & 3;
+  const int np = (p.K + 31) / 32;              // host guarantees np >= 3 when STAG
+  auto stage4 = [&](unsigned slot, const u32x4 rsA, const u32x4 rsB, int k0) {
+    const unsigned oob = (k0 + chunk4 * 8 >= p.K) ? 0x80000000u : 0u;
+    const unsigned d = lds0 + slot * HS_BYTES + wave * 1024;
+    dma16(rsA, d, voff4A0 | oob, (unsigned)(k0 * 2));
+    dma16(rsA, d + 8192, voff4A1 | oob, (unsigned)(k0 * 2));
+    dma16(rsB, d + 16384, voff4B0 | oob, (unsigned)(k0 * 2));
+    dma16(rsB, d + 16384 + 8192, voff4B1 | oob, (unsigned)(k0 * 2));
+  };
+  auto srdA = [&](int m) { return make_srd(p.A + (size_t)m * p.lda * 2, (unsigned)(min(BM, p.M - m) * p.lda * 2)); };
+  auto srdB = [&](int n) { return make_srd(p.B + (size_t)n * p.ldb * 2, (unsigned)(min(BN, p.N - n) * p.ldb * 2)); };
+
   if (idx >= len) return;
   unsigned it = idx;
   int m0, n0;
   tile_origin(base + it, m0, n0);
-  stage(0, m0, n0, 0);
-  unsigned gk = 0;   // global K-tile counter: ring slot = gk & 1
+  if constexpr (STAG) {
+    const u32x4 a = srdA(m0), b = srdB(n0);
+    stage4(0, a, b, 0);
+    stage4(1, a, b, 32);
+    stage4(2, a, b, 64);
+  } else {
+    stage(0, m0, n0, 0);
+  }
+  unsigned gk = 0;   // global K-tile (STAG: phase) counter: ring slot = gk & 1 (STAG: gk & 3)
   for (;;) {
     const bool has_next = it + gx < len;
     int m1 = 0, n1 = 0;
@@ -309,6 +364,65 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
 
+    if constexpr (STAG) {
+      const u32x4 rAc = srdA(m0), rBc = srdB(n0), rAn = srdA(m1), rBn = srdB(n1);
+      const int offA = (wm * 128 + l31) * 64, offB = (wn * 64 + l31) * 64;
+      const int c0 = (hi ^ sw4) << 4, c1 = ((2 + hi) ^ sw4) << 4;
+      // Every wave carries the fragments of a phase's SECOND k-step (ha, hb) across the next barrier: after
+      // barrier ph it issues the LDS reads of k-step 0 of phase ph and meanwhile runs the 8 MFMAs of k-step 1 of
+      // phase ph-1 from registers, so the MFMA pipe has work the moment the barrier opens (two waves per SIMD =
+      // 512 cycles of it) while the reads land.  Nobody reads half-slot ph-1 after barrier ph: it is refilled.
+      bf16x8 fa[4], fb[2], ha[4], hb[2];
+      auto mma = [&](const bf16x8 (&xa)[4], const bf16x8 (&xb)[2]) {
+        if (p.abl & 128) {   // ablation: no MFMA (fragments still consumed)
+          acc[0][0][0] += (float)xa[0][0] + (float)xa[1][0] + (float)xa[2][0] + (float)xa[3][0] + (float)xb[0][0] + (float)xb[1][0];
+          return;
+        }
+        if (SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+        if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+      };
+      const char *sA, *sB;
+      // wait for phase ph, open its barrier, refill the half-slot freed by it, start reading k-step 0
+      auto open_phase = [&](int ph) {
+        // the two newest phases (8 DMA instructions of this wave) may still be in flight.  After an epilogue
+        // (ph == 0) the queue also holds its stores, and at the tail of the last tile fewer phases were issued.
+        if (ph == 0 || (!has_next && ph + 2 >= np)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        WG_BARRIER_LDS();
+        const int q = ph + 3;
+        if (p.abl & 64) {   // ablation: no DMA in the main loop
+        } else if (q < np) stage4((gk + 3) & 3, rAc, rBc, q * 32);
+        else if (has_next) stage4((gk + 3) & 3, rAn, rBn, (q - np) * 32);
+        sA = smem + (gk & 3) * HS_BYTES + offA;
+        sB = smem + (gk & 3) * HS_BYTES + 16384 + offB;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) fa[mi] = *(const bf16x8*)(sA + mi * 2048 + c0);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) fb[ni] = *(const bf16x8*)(sB + ni * 2048 + c0);
+        ++gk;
+      };
+      auto read_step1 = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) ha[mi] = *(const bf16x8*)(sA + mi * 2048 + c1);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) hb[ni] = *(const bf16x8*)(sB + ni * 2048 + c1);
+      };
+      open_phase(0);
+      read_step1();
+      mma(fa, fb);
+      for (int ph = 1; ph < np; ++ph) {
+        open_phase(ph);
+        mma(ha, hb);
+        read_step1();
+        mma(fa, fb);
+      }
+      mma(ha, hb);
+    } else
     for (int kt = 0; kt < nkt; ++kt, ++gk) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -474,23 +588,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
 // loaders' `s_waitcnt vmcnt(0)` then covers DMA only, the storers' C tile drains underneath the next
 // tile's main loop, and all eight waves run the same MFMA main loop.  The DMA is issued from inline asm
 // (hidden from hipcc, which otherwise puts vmcnt(0) in front of every LDS read while a DMA may be pending).
-__device__ __forceinline__ u32x4 make_srd(const void* base, unsigned bytes) {
-  const unsigned long long b = (unsigned long long)base;
-  u32x4 s;
-  s[0] = (unsigned)b;
-  s[1] = (unsigned)(b >> 32) & 0xffffu;   // stride 0
-  s[2] = bytes;
-  s[3] = 0x00020000u;
-  return s;
-}
-__device__ __forceinline__ void dma16(const u32x4 srd, unsigned lds_addr, unsigned voff, unsigned soff) {
-  unsigned keep;
-  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
-               "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff) : "memory");
-}
-#define WG_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
 template <int EPI, bool SETPRIO>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt3_kernel(NTArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -968,9 +1065,10 @@ int ensure_attrs() {
   if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_nt<f32>): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
   e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
   if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_tn): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
-  const void* v2[4] = {(const void*)gemm_nt2_kernel<false, false>, (const void*)gemm_nt2_kernel<false, true>,
-                       (const void*)gemm_nt2_kernel<true, false>, (const void*)gemm_nt2_kernel<true, true>};
-  for (int i = 0; i < 4; ++i) {
+  const void* v2[5] = {(const void*)gemm_nt2_kernel<false, false>, (const void*)gemm_nt2_kernel<false, true>,
+                       (const void*)gemm_nt2_kernel<true, false>, (const void*)gemm_nt2_kernel<true, true>,
+                       (const void*)gemm_nt2_kernel<false, true, true>};
+  for (int i = 0; i < 5; ++i) {
     e = hipFuncSetAttribute(v2[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES);
     if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_nt2): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
   }
@@ -1019,7 +1117,14 @@ extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, co
   // shapes - while fused-activation / residual epilogues stay on the all-waves epilogue of v2 (their epilogue
   // maths is VALU-bound and wants all eight waves; measured 10..30 % slower under the role split);
   // 6: role split for every epilogue (experiments).
-  if (g_nt_variant >= 5 && !out_f32 && K >= 3 * BK && (epi == CLIPA_EPI_NONE || g_nt_variant >= 6)) {
+  // 7: staggered two-group main loop ("nt4") for every bf16-output GEMM; 8: nt4 for the fused epilogues, role
+  // split for plain ones.
+  if ((g_nt_variant == 7 || (g_nt_variant == 8 && epi != CLIPA_EPI_NONE)) && !out_f32 && K >= 96) {
+    const unsigned grid = (unsigned)(tiles < g_num_cu ? tiles : g_num_cu);
+    hipLaunchKernelGGL((gemm_nt2_kernel<false, true, true>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
+    return clipa_check_launch("gemm_nt4");
+  }
+  if (g_nt_variant >= 5 && !out_f32 && K >= 3 * BK && (epi == CLIPA_EPI_NONE || g_nt_variant == 6)) {
     const unsigned grid = (unsigned)(tiles < g_num_cu ? tiles : g_num_cu);
     if (epi == CLIPA_EPI_ACT) hipLaunchKernelGGL((gemm_nt3_kernel<CLIPA_EPI_ACT, true>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
     else if (epi == CLIPA_EPI_ADD) hipLaunchKernelGGL((gemm_nt3_kernel<CLIPA_EPI_ADD, true>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);

@@ -29,7 +29,7 @@ def _gather_fused(local, world_size, group=None):
         side = _side_stream(local.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            dist.all_gather_into_tensor(out, local, group=group)
+            dist.all_gather_into_tensor(out.view(torch.int16), local.view(torch.int16), group=group)   # pure byte movement
         cur.wait_stream(side)
         local.record_stream(side)
         out.record_stream(side)
@@ -41,7 +41,7 @@ def _gather_fused(local, world_size, group=None):
 def _reduce_scatter_fused(full, world_size, group=None):
     """reduce-scatter(SUM) [W*B, 2E] f32 -> [B, 2E]: backward of the differentiable all-gather."""
     rows = full.shape[0] // world_size
-    if not full.is_cuda:   # gloo (CPU test harness) has no reduce-scatter: all-reduce and keep our slice
+    if dist.get_backend(group) == "gloo":   # test harnesses only: gloo has no reduce-scatter, all-reduce and keep our slice
         full = full.contiguous().clone()
         dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
         r = dist.get_rank(group)

@@ -11,8 +11,9 @@ h = lib.load()
 h.clipa_debug_set.argtypes = [ctypes.c_int, ctypes.c_int]
 bf16 = torch.bfloat16
 torch.manual_seed(0)
-a = torch.randn(M, K, device="cuda").to(bf16)
-w = (torch.randn(N, K, device="cuda") * 0.05).to(bf16)
+PAD = int(os.environ.get("PAD", "0"))      # extra elements in the leading dimension of a and w (channel-camping probe)
+a = torch.randn(M, K + PAD, device="cuda").to(bf16)[:, :K]
+w = (torch.randn(N, K + PAD, device="cuda") * 0.05).to(bf16)[:, :K]
 bias = torch.randn(N, device="cuda")
 res = torch.randn(M, N, device="cuda").to(bf16)
 def run():
@@ -32,4 +33,4 @@ for rnd in range(7):
 for v in variants:
     t = sorted(times[v]); med = t[len(t) // 2]
     print(json.dumps({"M": M, "N": N, "K": K, "epi": epi, "nt": v[0], "abl": v[1], "ms_med": round(med, 4), "ms_min": round(t[0], 4),
-                      "tflops_med": round(2 * M * N * K / med / 1e9, 1)}))
+                      "tflops_med": round(2 * M * N * K / med / 1e9, 1), "pad": PAD}))
