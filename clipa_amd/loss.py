@@ -29,7 +29,7 @@ def _gather_fused(local, world_size, group=None):
         side = _side_stream(local.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            dist.all_gather_into_tensor(out.view(torch.int16), local.view(torch.int16), group=group)   # pure byte movement
+            dist.all_gather_into_tensor(out.view(torch.uint8), local.view(torch.uint8), group=group)   # pure byte movement
         cur.wait_stream(side)
         local.record_stream(side)
         out.record_stream(side)

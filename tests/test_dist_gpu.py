@@ -31,6 +31,22 @@ def _batch(world):
     return img, txt
 
 
+def _get(q, procs, limit=300):
+    """Queue read that gives up as soon as a worker has died (a crashed rank must not stall the suite)."""
+    import queue
+    import time
+    t0 = time.time()
+    while True:
+        try:
+            return q.get(timeout=2)
+        except queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs) or time.time() - t0 > limit:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                raise AssertionError("a worker rank died or timed out: " + str([p.exitcode for p in procs]))
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -52,10 +68,10 @@ def _worker(rank, world, port, q):
         out = ddp(img, txt)
         loss = loss_fn(**out, output_dict=True)["contrastive_loss"]
         loss.backward()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     torch.cuda.synchronize()
-    grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.grad is not None}
-    q.put((rank, losses, grads))
+    grads = {n: p.grad.detach().float().cpu().numpy() for n, p in model.named_parameters() if p.grad is not None}
+    q.put((rank, losses, grads))          # numpy: pickled by value (torch tensors travel as fds that die with the worker)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -69,7 +85,7 @@ def test_two_rank_step_equals_global_batch_step():
         p.start()
     got = {}
     for _ in range(world):
-        rank, losses, grads = q.get(timeout=600)
+        rank, losses, grads = _get(q, procs)
         got[rank] = (losses, grads)
     for p in procs:
         p.join(timeout=120)
@@ -90,7 +106,7 @@ def test_two_rank_step_equals_global_batch_step():
     assert abs(got[0][0][0] - got[0][0][1]) < 1e-6          # same weights, same batch -> same loss on step 2
     assert set(got[0][1]) == set(ref)
     for n, g in ref.items():
-        a, b = got[0][1][n], got[1][1][n]
+        a, b = torch.from_numpy(got[0][1][n]), torch.from_numpy(got[1][1][n])
         assert torch.equal(a, b), f"ranks disagree on {n} after the all-reduce"
         cos = torch.nn.functional.cosine_similarity(a.flatten(), g.flatten(), dim=0).item()
         rel = (a.norm() / g.norm().clamp_min(1e-12)).item()
@@ -132,6 +148,6 @@ def test_rccl_backend_single_rank_collectives_and_ddp():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_worker, args=(29771, q))
     p.start()
-    assert q.get(timeout=600) is True
+    assert _get(q, [p]) is True
     p.join(timeout=120)
     assert p.exitcode == 0
