@@ -1,4 +1,4 @@
-// Fused multi-head self-attention forward / backward for short sequences (L <= 288, head dim 64)
+// Fused multi-head self-attention forward / backward for short sequences (L <= 288, head dim 64 or 80)
 // on gfx950.  Replaces torch scaled_dot_product_attention as called from nn.MultiheadAttention in
 // clipa_torch/open_clip/transformer.py:209,223-236 (softmax(q.k^T/sqrt(dh) + mask).v, dropout 0;
 // mask = None for the image tower, additive causal triu(1)*-inf for text, transformer.py:618-624).
@@ -30,38 +30,59 @@ struct AttnArgs {
   int causal;
 };
 
-// chunk permutation of a 128-byte row (8 chunks of 16 B): conflict-free for both the direct
-// ds_read_b128 operand reads and the transposed ds_read_b64_tr_b16 reads (tools/lds_bank_sim.py)
+// Geometry per head dim.  dh = 64 (ViT-S/B/L, every text tower): 128-byte LDS rows, 4 k-steps, 2 output tiles.
+// dh = 80 (ViT-H/14, transformer.py:126 with head_width 80): 256-byte LDS rows of which 160 B carry data
+// (power-of-two row stride keeps the XOR swizzle), 5 k-steps, 3 output tiles whose last 16 columns are
+// never stored; one workgroup per CU instead of two.
+template <int DH>
+struct HD {
+  static constexpr int RB = DH == 64 ? 128 : 256;   // LDS row bytes
+  static constexpr int NCH = RB / 16;               // 16-byte chunk positions per row
+  static constexpr int KS = DH / 16;                // 16-wide reduction steps over the head dim
+  static constexpr int DT = (DH + 31) / 32;         // 32-wide output tiles over the head dim
+  static constexpr int WGS = DH == 64 ? 2 : 1;      // workgroups per CU the LDS image allows
+};
+
+// chunk permutation of an LDS row: conflict-free for both the direct ds_read_b128 operand reads and the
+// transposed ds_read_b64_tr_b16 reads (tools/lds_bank_sim.py) - 8 chunks per 128-B row, 16 per 256-B row
+template <int DH>
 __device__ __forceinline__ int swz_u(int row) {
-  return (((row >> 1) & 1) << 2) | ((row >> 2) & 1) | (((row >> 3) & 1) << 1);
+  if (DH == 64) return (((row >> 1) & 1) << 2) | ((row >> 2) & 1) | (((row >> 3) & 1) << 1);
+  return ((row & 3) << 2) | ((row >> 2) & 3);
 }
 
-// DMA rows [0, LP) x 128 B of one head into a swizzled LDS image; rows >= L read zeros (SRD bound)
+// DMA rows [0, LP) of one head into a swizzled LDS image; rows >= L and chunks >= dh read zeros
+template <int DH>
 __device__ __forceinline__ void dma_image(const __amdgpu_buffer_rsrc_t rs, char* img, int LP, long ld,
                                           int wave, int lane) {
-  for (int pc = wave; pc < LP / 8; pc += 4) {
-    const int row = pc * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ swz_u(row);
+  constexpr int NCH = HD<DH>::NCH, RPP = 1024 / HD<DH>::RB;
+  for (int pc = wave; pc < LP / RPP; pc += 4) {
+    const int row = pc * RPP + lane / NCH;
+    const int chunk = (lane & (NCH - 1)) ^ swz_u<DH>(row);
+    const unsigned oob = (chunk * 8 >= DH) ? 0x80000000u : 0u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(img + pc * 1024), 16,
-                                             (unsigned)(row * ld * 2 + chunk * 16), 0, 0, 0);
+                                             (unsigned)(row * ld * 2 + chunk * 16) | oob, 0, 0, 0);
   }
 }
 
 // direct operand fragment: lane -> image row (rowbase + l31), k-chunk 2*ks+hi
+template <int DH>
 __device__ __forceinline__ bf16x8 frag_direct(const char* img, int rowbase, int l31, int hi, int ks) {
-  return *(const bf16x8*)(img + (rowbase + l31) * 128 + (((2 * ks + hi) ^ swz_u(l31)) << 4));
+  return *(const bf16x8*)(img + (rowbase + l31) * HD<DH>::RB + (((2 * ks + hi) ^ swz_u<DH>(l31)) << 4));
 }
 
 // transposed operand fragment for a 16-wide reduction step: rows rowbase16 + {4hi+0..3, 8+4hi+0..3},
 // column (colbase + 16*q16 + i16) -> 8 k-slots matching the register order of a 32x32 C fragment
+template <int DH>
 __device__ __forceinline__ bf16x8 frag_trans(const char* img, int rowbase16, int colbase, int hi, int q16, int i16) {
+  constexpr int RB = HD<DH>::RB;
   const int col = colbase + 16 * q16 + 4 * (i16 & 3);
   const int r0 = rowbase16 + 4 * hi + (i16 >> 2);
   const int r1 = r0 + 8;
   const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) bf16x4*)(img + r0 * 128 + (((col >> 3) ^ swz_u(r0)) << 4) + (col & 7) * 2));
+      (__attribute__((address_space(3))) bf16x4*)(img + r0 * RB + (((col >> 3) ^ swz_u<DH>(r0)) << 4) + (col & 7) * 2));
   const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) bf16x4*)(img + r1 * 128 + (((col >> 3) ^ swz_u(r1)) << 4) + (col & 7) * 2));
+      (__attribute__((address_space(3))) bf16x4*)(img + r1 * RB + (((col >> 3) ^ swz_u<DH>(r1)) << 4) + (col & 7) * 2));
   bf16x8 f;
   f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3];
   f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
@@ -77,9 +98,11 @@ __device__ __forceinline__ bf16x8 pack_frag(const float* v) {
 
 // store a 32x32 fragment held as X^T[d][row] (lane: row = l31, d = 8*(r>>2)+4*hi+(r&3)) into a
 // row-major bf16 matrix: 4 consecutive d per store
-__device__ __forceinline__ void store_frag_T(char* base, long ld, long row, int col0, int hi, const f32x16& a, float mul) {
+__device__ __forceinline__ void store_frag_T(char* base, long ld, long row, int col0, int hi, const f32x16& a, float mul,
+                                             int ncols = 32) {
 #pragma unroll
   for (int qd = 0; qd < 4; ++qd) {
+    if (8 * qd >= ncols) continue;     // partial last tile of a head dim that is not a multiple of 32
     u32x2 w;
     w[0] = pack2bf(a[4 * qd + 0] * mul, a[4 * qd + 1] * mul);
     w[1] = pack2bf(a[4 * qd + 2] * mul, a[4 * qd + 3] * mul);
@@ -123,31 +146,31 @@ __device__ __forceinline__ void softmax_rows(f32x16 (&s)[NKT], const AttnArgs& p
   inv = 1.0f / sum;
 }
 
-template <int NKT>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
-  constexpr int LP = NKT * 32;
+template <int NKT, int DH>
+__global__ __launch_bounds__(256, HD<DH>::WGS) void attn_fwd_kernel(AttnArgs p) {
+  constexpr int LP = NKT * 32, RB = HD<DH>::RB, KS = HD<DH>::KS, DT = HD<DH>::DT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;
-  char* sV = smem + LP * 128;
+  char* sV = smem + LP * RB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5, q16 = (lane >> 4) & 1, i16 = lane & 15;
   const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
-  const size_t hoff = ((size_t)b * p.L * p.ld_qkv + (size_t)h * 64) * 2;
-  const unsigned nrec = (unsigned)((long)(p.L - 1) * p.ld_qkv * 2 + 128);
+  const size_t hoff = ((size_t)b * p.L * p.ld_qkv + (size_t)h * DH) * 2;
+  const unsigned nrec = (unsigned)((long)(p.L - 1) * p.ld_qkv * 2 + DH * 2);
   const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.q + hoff, nrec);
   const __amdgpu_buffer_rsrc_t rsK = make_rsrc(p.k + hoff, nrec);
   const __amdgpu_buffer_rsrc_t rsV = make_rsrc(p.v + hoff, nrec);
-  dma_image(rsK, sK, LP, p.ld_qkv, wave, lane);
-  dma_image(rsV, sV, LP, p.ld_qkv, wave, lane);
+  dma_image<DH>(rsK, sK, LP, p.ld_qkv, wave, lane);
+  dma_image<DH>(rsV, sV, LP, p.ld_qkv, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int qt = wave; qt < NKT; qt += 4) {
     const int qg = 32 * qt + l31;
-    bf16x8 fq[4];
+    bf16x8 fq[KS];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsQ, (unsigned)(qg * p.ld_qkv * 2 + (2 * ks + hi) * 16), 0, 0);
       fq[ks] = __builtin_bit_cast(bf16x8, t);
     }
@@ -158,15 +181,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
       if (p.causal && kt > qt) continue;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(sK, 32 * kt, l31, hi, ks), fq[ks], s[kt], 0, 0, 0);
+      for (int ks = 0; ks < KS; ++ks)
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct<DH>(sK, 32 * kt, l31, hi, ks), fq[ks], s[kt], 0, 0, 0);
     }
     float inv, m2;
     softmax_rows<NKT>(s, p, qt, qg, hi, inv, m2);
 
-    f32x16 o[2];
+    f32x16 o[DT];
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
 #pragma unroll
@@ -179,23 +202,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         for (int e = 0; e < 8; ++e) pv[e] = s[kt][8 * s2 + e];
         const bf16x8 pf = pack_frag(pv);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans(sV, 32 * kt + 16 * s2, 32 * dt, hi, q16, i16), pf, o[dt], 0, 0, 0);
+        for (int dt = 0; dt < DT; ++dt)
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans<DH>(sV, 32 * kt + 16 * s2, 32 * dt, hi, q16, i16), pf, o[dt], 0, 0, 0);
       }
     }
     if (qg < p.L) {
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-        store_frag_T(p.o, p.ld_o, (long)b * p.L + qg, h * 64 + 32 * dt, hi, o[dt], inv);
+      for (int dt = 0; dt < DT; ++dt)
+        store_frag_T(p.o, p.ld_o, (long)b * p.L + qg, h * DH + 32 * dt, hi, o[dt], inv, DH - 32 * dt);
       if (p.stats && hi == 0) *(float2*)(p.stats + ((size_t)blockIdx.x * p.L + qg) * 2) = make_float2(m2, inv);
     }
   }
 }
 
-// load the 4 k-step fragments of one 32-row tile straight from global memory (rows >= L read zeros)
-__device__ __forceinline__ void load_frags(const __amdgpu_buffer_rsrc_t rs, long ld, int row, int hi, bf16x8 (&f)[4]) {
+// load the k-step fragments of one 32-row tile straight from global memory (rows >= L read zeros)
+template <int KS>
+__device__ __forceinline__ void load_frags(const __amdgpu_buffer_rsrc_t rs, long ld, int row, int hi, bf16x8 (&f)[KS]) {
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
+  for (int ks = 0; ks < KS; ++ks)
     f[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(row * ld * 2 + (2 * ks + hi) * 16), 0, 0));
 }
 
@@ -203,23 +227,23 @@ __device__ __forceinline__ void load_frags(const __amdgpu_buffer_rsrc_t rs, long
 //   phase 1: K, V images; query-major sweep -> dQ   (q / dO / O rows of the wave's tile come from global)
 //   phase 2: Q, dO images; key-major sweep   -> dK, dV (k / v rows of the wave's tile come from global)
 // Probabilities are recomputed from the forward's (c*rowmax, 1/rowsum) statistics; D_q = <dO_q, O_q>.
-template <int NKT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
-  constexpr int LP = NKT * 32;
+template <int NKT, int DH>
+__global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) {
+  constexpr int LP = NKT * 32, RB = HD<DH>::RB, KS = HD<DH>::KS, DT = HD<DH>::DT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* img0 = smem;
-  char* img1 = smem + LP * 128;
-  float* sM = (float*)(smem + 2 * LP * 128);
+  char* img1 = smem + LP * RB;
+  float* sM = (float*)(smem + 2 * LP * RB);
   float* sL = sM + LP;
   float* sD = sL + LP;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5, q16 = (lane >> 4) & 1, i16 = lane & 15;
   const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
-  const size_t hoff = ((size_t)b * p.L * p.ld_qkv + (size_t)h * 64) * 2;
-  const size_t ooff = ((size_t)b * p.L * p.ld_o + (size_t)h * 64) * 2;
-  const unsigned nrec = (unsigned)((long)(p.L - 1) * p.ld_qkv * 2 + 128);
-  const unsigned nrec_o = (unsigned)((long)(p.L - 1) * p.ld_o * 2 + 128);
+  const size_t hoff = ((size_t)b * p.L * p.ld_qkv + (size_t)h * DH) * 2;
+  const size_t ooff = ((size_t)b * p.L * p.ld_o + (size_t)h * DH) * 2;
+  const unsigned nrec = (unsigned)((long)(p.L - 1) * p.ld_qkv * 2 + DH * 2);
+  const unsigned nrec_o = (unsigned)((long)(p.L - 1) * p.ld_o * 2 + DH * 2);
   const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.q + hoff, nrec), rsK = make_rsrc(p.k + hoff, nrec),
                                rsV = make_rsrc(p.v + hoff, nrec), rsDO = make_rsrc(p.d_o + ooff, nrec_o),
                                rsO = make_rsrc(p.o_in + ooff, nrec_o);
@@ -227,21 +251,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   const float* stats = p.stats + (size_t)blockIdx.x * p.L * 2;
 
   // ---- phase 1: dQ ------------------------------------------------------------------------------
-  dma_image(rsK, img0, LP, p.ld_qkv, wave, lane);
-  dma_image(rsV, img1, LP, p.ld_qkv, wave, lane);
+  dma_image<DH>(rsK, img0, LP, p.ld_qkv, wave, lane);
+  dma_image<DH>(rsV, img1, LP, p.ld_qkv, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int qt = wave; qt < NKT; qt += 4) {
     const int qg = 32 * qt + l31;
-    bf16x8 fq[4], fdo[4], fo[4];
-    load_frags(rsQ, p.ld_qkv, qg, hi, fq);
-    load_frags(rsDO, p.ld_o, qg, hi, fdo);
-    load_frags(rsO, p.ld_o, qg, hi, fo);
+    bf16x8 fq[KS], fdo[KS], fo[KS];
+    load_frags<KS>(rsQ, p.ld_qkv, qg, hi, fq);
+    load_frags<KS>(rsDO, p.ld_o, qg, hi, fdo);
+    load_frags<KS>(rsO, p.ld_o, qg, hi, fo);
     float2 st = make_float2(0.f, 0.f);                 // padded queries: inv = 0 -> P = 0
     if (qg < p.L) st = *(const float2*)(stats + qg * 2);
     float Dq = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       float a[8], o8[8];
       unpack8(__builtin_bit_cast(u32x4, fdo[ks]), a);
       unpack8(__builtin_bit_cast(u32x4, fo[ks]), o8);
@@ -251,9 +275,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
     Dq += __shfl_xor(Dq, 32, 64);
     if (hi == 0) { sM[qg] = st.x; sL[qg] = st.y; sD[qg] = Dq; }
     const int lim2 = (p.causal ? min(p.L, qg + 1) : p.L) - 4 * hi;
-    f32x16 dq[2];
+    f32x16 dq[DT];
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 #pragma unroll
@@ -263,9 +287,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(img0, 32 * kt, l31, hi, ks), fq[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(img1, 32 * kt, l31, hi, ks), fdo[ks], dp, 0, 0, 0);
+      for (int ks = 0; ks < KS; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct<DH>(img0, 32 * kt, l31, hi, ks), fq[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct<DH>(img1, 32 * kt, l31, hi, ks), fdo[ks], dp, 0, 0, 0);
       }
       const bool full = (32 * kt + 32 <= p.L) && (!p.causal || kt < qt);
       float ds[16];
@@ -279,32 +303,32 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 dsf = pack_frag(ds + 8 * s2);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans(img0, 32 * kt + 16 * s2, 32 * dt, hi, q16, i16), dsf, dq[dt], 0, 0, 0);
+        for (int dt = 0; dt < DT; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans<DH>(img0, 32 * kt + 16 * s2, 32 * dt, hi, q16, i16), dsf, dq[dt], 0, 0, 0);
       }
     }
     if (qg < p.L) {
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-        store_frag_T(p.dq, p.ld_dqkv, (long)b * p.L + qg, h * 64 + 32 * dt, hi, dq[dt], 1.0f);
+      for (int dt = 0; dt < DT; ++dt)
+        store_frag_T(p.dq, p.ld_dqkv, (long)b * p.L + qg, h * DH + 32 * dt, hi, dq[dt], 1.0f, DH - 32 * dt);
     }
   }
   __syncthreads();   // everyone is done with the K / V images (and the statistics are in LDS)
 
   // ---- phase 2: dK, dV --------------------------------------------------------------------------
-  dma_image(rsQ, img0, LP, p.ld_qkv, wave, lane);
-  dma_image(rsDO, img1, LP, p.ld_o, wave, lane);
+  dma_image<DH>(rsQ, img0, LP, p.ld_qkv, wave, lane);
+  dma_image<DH>(rsDO, img1, LP, p.ld_o, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kt = wave; kt < NKT; kt += 4) {
     const int kg = 32 * kt + l31;
     const int kgc = l31 - 4 * hi;      // causal test inside the diagonal tile: key <= query
-    bf16x8 fk[4], fv[4];
-    load_frags(rsK, p.ld_qkv, kg, hi, fk);
-    load_frags(rsV, p.ld_qkv, kg, hi, fv);
-    f32x16 dk[2], dv[2];
+    bf16x8 fk[KS], fv[KS];
+    load_frags<KS>(rsK, p.ld_qkv, kg, hi, fk);
+    load_frags<KS>(rsV, p.ld_qkv, kg, hi, fv);
+    f32x16 dk[DT], dv[DT];
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
     for (int qt = (p.causal ? kt : 0); qt < NKT; ++qt) {
@@ -312,9 +336,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(img0, 32 * qt, l31, hi, ks), fk[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(img1, 32 * qt, l31, hi, ks), fv[ks], dp, 0, 0, 0);
+      for (int ks = 0; ks < KS; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct<DH>(img0, 32 * qt, l31, hi, ks), fk[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct<DH>(img1, 32 * qt, l31, hi, ks), fv[ks], dp, 0, 0, 0);
       }
       float pr[16], ds[16];
 #pragma unroll
@@ -342,49 +366,49 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
         const bf16x8 pf = pack_frag(pr + 8 * s2);
         const bf16x8 dsf = pack_frag(ds + 8 * s2);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans(img1, 32 * qt + 16 * s2, 32 * dt, hi, q16, i16), pf, dv[dt], 0, 0, 0);
-          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans(img0, 32 * qt + 16 * s2, 32 * dt, hi, q16, i16), dsf, dk[dt], 0, 0, 0);
+        for (int dt = 0; dt < DT; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans<DH>(img1, 32 * qt + 16 * s2, 32 * dt, hi, q16, i16), pf, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans<DH>(img0, 32 * qt + 16 * s2, 32 * dt, hi, q16, i16), dsf, dk[dt], 0, 0, 0);
         }
       }
     }
     if (kg < p.L) {
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        store_frag_T(p.dk, p.ld_dqkv, (long)b * p.L + kg, h * 64 + 32 * dt, hi, dk[dt], 1.0f);
-        store_frag_T(p.dv, p.ld_dqkv, (long)b * p.L + kg, h * 64 + 32 * dt, hi, dv[dt], 1.0f);
+      for (int dt = 0; dt < DT; ++dt) {
+        store_frag_T(p.dk, p.ld_dqkv, (long)b * p.L + kg, h * DH + 32 * dt, hi, dk[dt], 1.0f, DH - 32 * dt);
+        store_frag_T(p.dv, p.ld_dqkv, (long)b * p.L + kg, h * DH + 32 * dt, hi, dv[dt], 1.0f, DH - 32 * dt);
       }
     }
   }
 }
 
-template <int NKT>
+template <int NKT, int DH>
 int launch_fwd(const AttnArgs& a, hipStream_t st) {
-  const int lds = 2 * NKT * 32 * 128;
+  const int lds = 2 * NKT * 32 * HD<DH>::RB;
   static bool done = false;
   if (!done) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NKT, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { clipa_set_error("attn_fwd attr: %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
     done = true;
   }
-  hipLaunchKernelGGL(attn_fwd_kernel<NKT>, dim3((unsigned)(a.B * a.H)), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((attn_fwd_kernel<NKT, DH>), dim3((unsigned)(a.B * a.H)), dim3(256), lds, st, a);
   return clipa_check_launch("attn_fwd");
 }
-template <int NKT>
+template <int NKT, int DH>
 int launch_bwd(const AttnArgs& a, hipStream_t st) {
-  const int lds = 2 * NKT * 32 * 128 + 3 * NKT * 32 * 4;
+  const int lds = 2 * NKT * 32 * HD<DH>::RB + 3 * NKT * 32 * 4;
   static bool done = false;
   if (!done) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NKT, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { clipa_set_error("attn_bwd attr: %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
     done = true;
   }
-  hipLaunchKernelGGL(attn_bwd_kernel<NKT>, dim3((unsigned)(a.B * a.H)), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((attn_bwd_kernel<NKT, DH>), dim3((unsigned)(a.B * a.H)), dim3(256), lds, st, a);
   return clipa_check_launch("attn_bwd");
 }
 
 int check_args(int64_t B, int64_t H, int64_t L, int64_t dh, int64_t ld_qkv, int64_t ld_o) {
-  if (dh != 64) { clipa_set_error("attention: head dim %ld unsupported (64 only)", (long)dh); return CLIPA_ERR_ARG; }
+  if (dh != 64 && dh != 80) { clipa_set_error("attention: head dim %ld unsupported (64 and 80 only)", (long)dh); return CLIPA_ERR_ARG; }
   if (L <= 0 || L > 288) { clipa_set_error("attention: L=%ld outside (0, 288]", (long)L); return CLIPA_ERR_ARG; }
   if (ld_qkv % 8 != 0 || ld_o % 8 != 0) { clipa_set_error("attention: row strides must be multiples of 8 elements"); return CLIPA_ERR_ARG; }
   if (B * H <= 0 || B * H > 0x7fffffffL) { clipa_set_error("attention: bad B*H"); return CLIPA_ERR_ARG; }
@@ -393,14 +417,17 @@ int check_args(int64_t B, int64_t H, int64_t L, int64_t dh, int64_t ld_qkv, int6
 
 }  // namespace
 
-#define ATTN_DISPATCH(fn, a, st)                                    \
-  switch (((a).L + 31) / 32) {                                     \
-    case 1: return fn<1>(a, st); case 2: return fn<2>(a, st);      \
-    case 3: return fn<3>(a, st); case 4: return fn<4>(a, st);      \
-    case 5: return fn<5>(a, st); case 6: return fn<6>(a, st);      \
-    case 7: return fn<7>(a, st); case 8: return fn<8>(a, st);      \
-    default: return fn<9>(a, st);                                   \
+#define ATTN_DISPATCH_DH(fn, DH, a, st)                                     \
+  switch (((a).L + 31) / 32) {                                               \
+    case 1: return fn<1, DH>(a, st); case 2: return fn<2, DH>(a, st);        \
+    case 3: return fn<3, DH>(a, st); case 4: return fn<4, DH>(a, st);        \
+    case 5: return fn<5, DH>(a, st); case 6: return fn<6, DH>(a, st);        \
+    case 7: return fn<7, DH>(a, st); case 8: return fn<8, DH>(a, st);        \
+    default: return fn<9, DH>(a, st);                                        \
   }
+#define ATTN_DISPATCH(fn, dh, a, st)                 \
+  if ((dh) == 80) { ATTN_DISPATCH_DH(fn, 80, a, st) } \
+  ATTN_DISPATCH_DH(fn, 64, a, st)
 
 extern "C" int clipa_attention_fwd(const void* q, const void* k, const void* v, void* out, float* stats,
                                    int64_t B, int64_t H, int64_t L, int64_t dh, int64_t ld_qkv, int64_t ld_o,
@@ -411,7 +438,7 @@ extern "C" int clipa_attention_fwd(const void* q, const void* k, const void* v, 
   a.q = (const char*)q; a.k = (const char*)k; a.v = (const char*)v; a.ld_qkv = ld_qkv;
   a.o = (char*)out; a.ld_o = ld_o; a.B = (int)B; a.H = (int)H; a.L = (int)L; a.scale = scale; a.causal = causal;
   a.stats = stats;
-  ATTN_DISPATCH(launch_fwd, a, (hipStream_t)stream)
+  ATTN_DISPATCH(launch_fwd, dh, a, (hipStream_t)stream)
 }
 
 extern "C" int clipa_attention_bwd(const void* q, const void* k, const void* v, const void* out,
@@ -428,5 +455,5 @@ extern "C" int clipa_attention_bwd(const void* q, const void* k, const void* v, 
   a.dq = (char*)dq; a.dk = (char*)dk; a.dv = (char*)dv; a.ld_dqkv = ld_dqkv;
   a.B = (int)B; a.H = (int)H; a.L = (int)L; a.scale = scale; a.causal = causal;
   a.stats = const_cast<float*>(stats);
-  ATTN_DISPATCH(launch_bwd, a, (hipStream_t)stream)
+  ATTN_DISPATCH(launch_bwd, dh, a, (hipStream_t)stream)
 }

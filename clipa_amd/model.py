@@ -138,8 +138,8 @@ class Transformer(nn.Module):
 
     def __init__(self, width, layers, heads, mlp_ratio=4.0, act=ops.ACT_GELU_ERF):
         super().__init__()
-        if width % heads != 0 or width // heads != 64:
-            _unsupported(f"head dim {width // heads if heads else '?'} (the fused attention kernel covers 64)")
+        if width % heads != 0 or width // heads not in (64, 80):
+            _unsupported(f"head dim {width // heads if heads else '?'} (the fused attention kernels cover 64 and 80)")
         self.width, self.layers, self.heads, self.act = width, layers, heads, act
         self.grad_checkpointing = False
         # MI355X engine knob (no reference counterpart): with grad checkpointing on, the first `keep_blocks`

@@ -45,6 +45,11 @@ CASES = {
                        "ln_pre": False, "pool_style": "big_vision_gap"},
         "text_cfg": {"context_length": 8, "vocab_size": 512, "width": 64, "heads": 1, "layers": 1,
                      "pool_style": "big_vision_last", "attention_mask": False}}),
+    # ViT-H/14 flavour: 14 px patches (588-wide im2col rows, not a multiple of 8), head_width 80
+    "h14_dh80": dict(B=8, S=42, seed=14, cfg={
+        "embed_dim": 64,
+        "vision_cfg": {"image_size": 42, "layers": 2, "width": 160, "head_width": 80, "patch_size": 14},
+        "text_cfg": {"context_length": 16, "vocab_size": 512, "width": 128, "heads": 2, "layers": 2}}),
 }
 
 
@@ -146,9 +151,12 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
     ref_model, ref_loss, _ = ref_loader.load()
+    only = sys.argv[1:]                      # optional: regenerate just the named fixtures
     for name, spec in CASES.items():
-        run_case(name, spec, ref_model, ref_loss)
-    run_dist()
+        if not only or name in only:
+            run_case(name, spec, ref_model, ref_loss)
+    if not only or "dist_loss_w2" in only:
+        run_dist()
 
 
 if __name__ == "__main__":

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-MODEL_CASES = ["cls_erf", "gap_sincos_tanh", "bigvision_quick"]
+MODEL_CASES = ["cls_erf", "gap_sincos_tanh", "bigvision_quick", "h14_dh80"]
 
 
 def pytest_configure(config):

@@ -130,10 +130,11 @@ def test_layernorm(D, xdt, ydt):
 
 
 # -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dh", [64, 80])       # 80 = ViT-H/14 (head_width 80)
 @pytest.mark.parametrize("B,H,L,causal", [(2, 3, 26, False), (3, 2, 50, False), (2, 2, 77, True), (2, 4, 197, False),
                                           (1, 2, 257, False), (2, 1, 8, True), (2, 2, 32, True), (1, 2, 288, True)])
-def test_attention(B, H, L, causal):
-    D = 64 * H
+def test_attention(B, H, L, causal, dh):
+    D = dh * H
     qkv = rnd(B * L, 3 * D, seed=30 + L, scale=1.2)
     dout = rnd(B * L, D, seed=31 + L)
     x = qkv.double().reshape(B, L, 3 * D).requires_grad_(True)
@@ -146,10 +147,11 @@ def test_attention(B, H, L, causal):
     check("dqkv", dq.reshape(B, L, 3 * D), x.grad, 2 ** -5, 2e-2)
 
 
-def test_attention_reads_packed_projection_in_place():
+@pytest.mark.parametrize("dh", [64, 80])
+def test_attention_reads_packed_projection_in_place(dh):
     """q/k/v are column blocks of a wider buffer (row stride != 3D) - no head-major copy is made."""
     B, H, L = 2, 2, 50
-    D = 64 * H
+    D = dh * H
     wide = rnd(B * L, 3 * D + 64, seed=40).to(DEV)
     qkv = wide[:, :3 * D]
     ref = ops().attention_fwd(qkv.contiguous(), B, L, H, False)
