@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="local (per-GPU) batch")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "amp_bf16"],
                     help="bf16 = reference 'bf16' mode (bf16 weights); amp_bf16 = fp32 master weights")
-    ap.add_argument("--keep-blocks", default="auto", help="'auto' or 'NV,NT': blocks per tower that skip recompute")
+    ap.add_argument("--keep-blocks", default="auto", help="'auto' or 'LV,LT[,MV,MT]': light-kept (and medium-kept) blocks per tower (image, text)")
     ap.add_argument("--keep-fraction", type=float, default=0.88, help="share of the free HBM 'auto' may spend")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="pairs per CPU-baseline step")
@@ -171,13 +171,13 @@ def main():
     # Activation policy: every block recomputes in backward (the reference's --grad-checkpointing) except the
     # first `keep` blocks of each tower, which keep their GEMM / attention outputs in the HBM that is left over.
     # "auto" measures the peak of one all-recompute step and spends ~85 % of the remaining HBM.
-    def set_keep(nv, nt):
-        model.visual.transformer.keep_blocks, model.transformer.keep_blocks = nv, nt
+    def set_keep(kv, kt, mv=0, mt=0):
+        model.visual.transformer.keep_blocks, model.transformer.keep_blocks = kv, kt
+        model.visual.transformer.medium_blocks, model.transformer.medium_blocks = mv, mt
 
-    keep_v = keep_t = 0
+    keep_v = keep_t = med_v = med_t = 0
     L_img = (args.image_size // cfg["vision_cfg"]["patch_size"]) ** 2 + 1
-    per_v = model.visual.transformer.light_keep_bytes(B * L_img)
-    per_t = model.transformer.light_keep_bytes(B * args.ctx)
+    vt, tt = model.visual.transformer, model.transformer
     warm = args.warmup
     if args.keep_blocks == "auto":
         total_mem = torch.cuda.get_device_properties(dev).total_memory
@@ -186,11 +186,21 @@ def main():
         torch.cuda.synchronize()
         peak = torch.cuda.max_memory_allocated(dev)
         budget = int(args.keep_fraction * (total_mem - peak)) - (6 << 30)
-        keep_v = max(0, min(cfg["vision_cfg"]["layers"], budget // per_v))
-        keep_t = max(0, min(cfg["text_cfg"]["layers"], (budget - keep_v * per_v) // per_t))
+        # Spend the budget where a byte saves the most recompute FLOPs: "medium" tier first (drops LN1, in-proj,
+        # attention, out-proj: ~17.5 of a block's 25.5 D^2 units for 5 D bytes per token), image tower before
+        # text (wider), then upgrades medium -> "light" (the remaining 8 units for 4 more D bytes).
+        mv_b, mt_b = vt.medium_keep_bytes(B * L_img), tt.medium_keep_bytes(B * args.ctx)
+        lv_b, lt_b = vt.light_keep_bytes(B * L_img), tt.light_keep_bytes(B * args.ctx)
+        med_v = max(0, min(cfg["vision_cfg"]["layers"], budget // mv_b)); budget -= med_v * mv_b
+        med_t = max(0, min(cfg["text_cfg"]["layers"], budget // mt_b)); budget -= med_t * mt_b
+        keep_v = max(0, min(med_v, budget // (lv_b - mv_b))); budget -= keep_v * (lv_b - mv_b)
+        keep_t = max(0, min(med_t, budget // (lt_b - mt_b)))
+        med_v, med_t = med_v - keep_v, med_t - keep_t
     else:
-        keep_v, keep_t = (int(v) for v in args.keep_blocks.split(","))
-    set_keep(int(keep_v), int(keep_t))
+        vals = [int(v) for v in args.keep_blocks.split(",")]
+        keep_v, keep_t = vals[0], vals[1]
+        med_v, med_t = (vals[2], vals[3]) if len(vals) >= 4 else (0, 0)
+    set_keep(int(keep_v), int(keep_t), int(med_v), int(med_t))
     for _ in range(warm):
         step()
     fence()
@@ -230,7 +240,7 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.model}@{args.image_size} + text-{args.ctx}, local batch {B}, "
                                    f"global batch {B * world}, InfoNCE local_loss+gather_with_grad, AdamW, "
-                                   f"block recompute except {int(keep_v)}+{int(keep_t)} (image+text) kept blocks", "precision": args.precision, "parallelism": f"dp{world}",
+                                   f"block recompute except {int(keep_v)}+{int(keep_t)} light-kept and {int(med_v)}+{int(med_t)} medium-kept (image+text) blocks", "precision": args.precision, "parallelism": f"dp{world}",
                        "global_batch": B * world, "train_gflop_per_pair": round(gf, 2)},
             "model_flops_util": round(pairs_s / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4),
             "loss": round(last_loss, 4), "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),

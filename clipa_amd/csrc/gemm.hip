@@ -347,6 +347,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
     stage4(0, a, b, 0);
     stage4(1, a, b, 32);
     stage4(2, a, b, 64);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WG_BARRIER_LDS();
   } else {
     stage(0, m0, n0, 0);
   }
@@ -368,60 +370,57 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
       const u32x4 rAc = srdA(m0), rBc = srdB(n0), rAn = srdA(m1), rBn = srdB(n1);
       const int offA = (wm * 128 + l31) * 64, offB = (wn * 64 + l31) * 64;
       const int c0 = (hi ^ sw4) << 4, c1 = ((2 + hi) ^ sw4) << 4;
-      // Every wave carries the fragments of a phase's SECOND k-step (ha, hb) across the next barrier: after
-      // barrier ph it issues the LDS reads of k-step 0 of phase ph and meanwhile runs the 8 MFMAs of k-step 1 of
-      // phase ph-1 from registers, so the MFMA pipe has work the moment the barrier opens (two waves per SIMD =
-      // 512 cycles of it) while the reads land.  Nobody reads half-slot ph-1 after barrier ph: it is refilled.
-      bf16x8 fa[4], fb[2], ha[4], hb[2];
-      auto mma = [&](const bf16x8 (&xa)[4], const bf16x8 (&xb)[2]) {
-        if (p.abl & 128) {   // ablation: no MFMA (fragments still consumed)
-          acc[0][0][0] += (float)xa[0][0] + (float)xa[1][0] + (float)xa[2][0] + (float)xa[3][0] + (float)xb[0][0] + (float)xb[1][0];
-          return;
+      // PING-PONG: every wave alternates a LOAD phase (12 ds_read_b128 = both k-steps of one slab into
+      // registers, its 4 DMA pieces of the slab three ahead, the counted vmcnt) and a COMPUTE phase (16 MFMAs
+      // from those registers), one s_barrier after each.  Group 1 (waves 4-7, the second wave of every SIMD)
+      // runs one barrier behind group 0, so on each SIMD one wave's MFMA block always sits beside the other
+      // wave's LDS/DMA phase: the LDS latency is never on the MFMA pipe's critical path.
+      //   slab s is read by group 0 in phase 2s and by group 1 in phase 2s+1; its half-slot is refilled (slab
+      //   s+4) from phase 2s+2 on, i.e. in LOAD(s+1) of either group; a wave waits for its own pieces of slab
+      //   s+1 at the end of LOAD(s) (the two newer slabs = 8 instructions may stay in flight), two barriers
+      //   before anyone reads them.
+      bf16x8 fa[2][4], fb[2][2];
+      if (wm == 1) WG_BARRIER_LDS();
+      for (int sl = 0; sl < np; ++sl, ++gk) {
+        // ---- LOAD
+        const char* sA = smem + (gk & 3) * HS_BYTES + offA;
+        const char* sB = smem + (gk & 3) * HS_BYTES + 16384 + offB;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) fa[0][mi] = *(const bf16x8*)(sA + mi * 2048 + c0);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) fb[0][ni] = *(const bf16x8*)(sB + ni * 2048 + c0);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) fa[1][mi] = *(const bf16x8*)(sA + mi * 2048 + c1);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) fb[1][ni] = *(const bf16x8*)(sB + ni * 2048 + c1);
+        {
+          const int q = sl + 3;                 // refill the half-slot both groups finished reading one phase ago
+          if (q < np) stage4((gk + 3) & 3, rAc, rBc, q * 32);
+          else if (has_next) stage4((gk + 3) & 3, rAn, rBn, (q - np) * 32);
         }
+        // own pieces of slab sl+1 must have landed (slabs 0..2 of a tile are drained before the loop starts).
+        // The two newer slabs may stay in flight; at the tail of the last tile nothing newer was issued.
+        if (sl >= 2) {
+          if (!has_next && sl + 3 >= np) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
+        WG_BARRIER_LDS();
+        // ---- COMPUTE
         if (SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+              acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][ni], fa[ks][mi], acc[ni][mi], 0, 0, 0);
         if (SETPRIO) __builtin_amdgcn_s_setprio(0);
-      };
-      const char *sA, *sB;
-      // wait for phase ph, open its barrier, refill the half-slot freed by it, start reading k-step 0
-      auto open_phase = [&](int ph) {
-        // the two newest phases (8 DMA instructions of this wave) may still be in flight.  After an epilogue
-        // (ph == 0) the queue also holds its stores, and at the tail of the last tile fewer phases were issued.
-        if (ph == 0 || (!has_next && ph + 2 >= np)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         WG_BARRIER_LDS();
-        const int q = ph + 3;
-        if (p.abl & 64) {   // ablation: no DMA in the main loop
-        } else if (q < np) stage4((gk + 3) & 3, rAc, rBc, q * 32);
-        else if (has_next) stage4((gk + 3) & 3, rAn, rBn, (q - np) * 32);
-        sA = smem + (gk & 3) * HS_BYTES + offA;
-        sB = smem + (gk & 3) * HS_BYTES + 16384 + offB;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) fa[mi] = *(const bf16x8*)(sA + mi * 2048 + c0);
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) fb[ni] = *(const bf16x8*)(sB + ni * 2048 + c0);
-        ++gk;
-      };
-      auto read_step1 = [&]() {
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) ha[mi] = *(const bf16x8*)(sA + mi * 2048 + c1);
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) hb[ni] = *(const bf16x8*)(sB + ni * 2048 + c1);
-      };
-      open_phase(0);
-      read_step1();
-      mma(fa, fb);
-      for (int ph = 1; ph < np; ++ph) {
-        open_phase(ph);
-        mma(ha, hb);
-        read_step1();
-        mma(fa, fb);
       }
-      mma(ha, hb);
+      if (wm == 0) WG_BARRIER_LDS();          // group 1's last COMPUTE phase: both groups are aligned again
+      // drain the next tile's first three slabs (issued by the last three LOAD phases) before the epilogue's
+      // own loads and stores enter the queue; the epilogue's barriers make them visible to every wave
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else
     for (int kt = 0; kt < nkt; ++kt, ++gk) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -867,6 +866,236 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt3_kernel(NTArgs p) {
     n0 = n1;
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// gemm_nt v5: PING-PONG main loop + WAVE ROLES, plain / bias epilogue (the shapes v3 used to take).
+//   * K is walked in slabs of 32 through four 32 KiB half-slots (A [256][32] + B [256][32], 64-byte rows,
+//     chunk ^= (row>>2)&3).  Every wave alternates LOAD (12 ds_read_b128 = one slab's fragments) and COMPUTE
+//     (16 MFMAs from registers) with an s_barrier after each; group 1 (waves 4-7 = the second wave of every
+//     SIMD) runs one barrier behind group 0, so each SIMD always has one wave in its MFMA block beside the
+//     other wave's LDS phase.
+//   * Group 0 issues every LDS-DMA (all 32 pieces of slab s+3 in LOAD(s), counted `vmcnt(16)`) and never
+//     stores; group 1 issues every global store and never waits on vmcnt.  Stores and loads share one
+//     counter per wave, and a store retires only after its HBM round trip: in v2 that latency (not the
+//     bandwidth - staggering the workgroups changed nothing) sat in front of the next tile's first DMA wait.
+//   * Epilogue: owners convert their 64-row pass into one of two 32 KiB windows (the C window and the ring
+//     half-slot the last slab was read from) while group 1 copies the previous pass to global; the bias
+//     arrives by DMA in the idle C window and is folded into the accumulators before the last slab.
+__global__ __launch_bounds__(NTHREADS) void gemm_nt5_kernel(NTArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wm = wave >> 2, wn = wave & 3;
+  const bool loader = wm == 0;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  char* cb = smem + CBUF_OFF;
+
+  const int tilesN = (p.N + BN - 1) / BN;
+  const int tilesM = (p.M + BM - 1) / BM;
+  const unsigned ntiles = (unsigned)(tilesM * tilesN);
+  const unsigned G = gridDim.x, xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+  const unsigned gx = (G - xcd + 7u) >> 3;
+  const unsigned q8 = ntiles >> 3, r8 = ntiles & 7u;
+  const unsigned base = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const unsigned len = q8 + (xcd < r8 ? 1u : 0u);
+  auto tile_origin = [&](unsigned t, int& m0, int& n0) {
+    const int GM = 4;
+    const int per = GM * tilesN;
+    const int g = (int)t / per, r = (int)t - g * per;
+    const int gm = min(GM, tilesM - g * GM);
+    const int tn = r / gm, mm = r - tn * gm;
+    m0 = (g * GM + mm) * BM;
+    n0 = tn * BN;
+  };
+
+  // loader wave lw moves pieces lw, lw+4, lw+8, lw+12 (16 rows x 64 B each) of the A image and of the B image
+  const int lw = wave & 3;
+  const int chunk4 = (lane & 3) ^ ((lane >> 4) & 3);
+  const int row4 = lw * 16 + (lane >> 2);
+  const unsigned voffA = (unsigned)(row4 * p.lda * 2 + chunk4 * 16), voffB = (unsigned)(row4 * p.ldb * 2 + chunk4 * 16);
+  const unsigned stepA = (unsigned)(64 * p.lda * 2), stepB = (unsigned)(64 * p.ldb * 2);
+  const int sw4 = (l31 >> 2) & 3;
+  const int np = (p.K + 31) / 32;              // host guarantees np >= 4
+  auto stage5 = [&](unsigned slot, const u32x4 rsA, const u32x4 rsB, int k0) {
+    const unsigned oob = (k0 + chunk4 * 8 >= p.K) ? 0x80000000u : 0u;
+    const unsigned d = lds0 + slot * HS_BYTES + lw * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma16(rsA, d + j * 4096, (voffA + j * stepA) | oob, (unsigned)(k0 * 2));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma16(rsB, d + 16384 + j * 4096, (voffB + j * stepB) | oob, (unsigned)(k0 * 2));
+  };
+  auto srdA = [&](int m) { return make_srd(p.A + (size_t)m * p.lda * 2, (unsigned)(min(BM, p.M - m) * p.lda * 2)); };
+  auto srdB = [&](int n) { return make_srd(p.B + (size_t)n * p.ldb * 2, (unsigned)(min(BN, p.N - n) * p.ldb * 2)); };
+
+  if (idx >= len) return;
+  unsigned it = idx;
+  int m0, n0;
+  tile_origin(base + it, m0, n0);
+  if (loader) {
+    const u32x4 a = srdA(m0), b = srdB(n0);
+    stage5(0, a, b, 0);
+    stage5(1, a, b, 32);
+    stage5(2, a, b, 64);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  WG_BARRIER_LDS();
+  const int offA = (wm * 128 + l31) * 64, offB = (wn * 64 + l31) * 64;
+  const int c0 = (hi ^ sw4) << 4, c1 = ((2 + hi) ^ sw4) << 4;
+  unsigned gk = 0;   // global slab counter: half-slot = gk & 3
+  for (;;) {
+    const bool has_next = it + gx < len;
+    int m1 = 0, n1 = 0;
+    if (has_next) tile_origin(base + it + gx, m1, n1);
+    const u32x4 rAc = srdA(m0), rBc = srdB(n0), rAn = srdA(m1), rBn = srdB(n1);
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+
+    bf16x8 fa[2][4], fb[2][2];
+    if (wm == 1) WG_BARRIER_LDS();            // group 1 runs one barrier behind
+    for (int sl = 0; sl < np; ++sl, ++gk) {
+      // ---- LOAD: slab sl (landed two barriers ago) -> registers
+      const char* sA = smem + (gk & 3) * HS_BYTES + offA;
+      const char* sB = smem + (gk & 3) * HS_BYTES + 16384 + offB;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) fa[0][mi] = *(const bf16x8*)(sA + mi * 2048 + c0);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) fb[0][ni] = *(const bf16x8*)(sB + ni * 2048 + c0);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) fa[1][mi] = *(const bf16x8*)(sA + mi * 2048 + c1);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) fb[1][ni] = *(const bf16x8*)(sB + ni * 2048 + c1);
+      if (loader) {
+        // the bias row of this tile rides the DMA queue into the C window (idle until the epilogue; the copy of
+        // the previous tile's last pass out of it ended before this tile's first barrier)
+        if (sl == 1 && wave == 0 && p.bias)
+          dma16(make_srd(p.bias + n0, (unsigned)((p.N - n0) * 4)), lds0 + CBUF_OFF, (unsigned)(lane * 16), 0u);
+        // slab sl+3 into the half-slot of slab sl-1 (group 1 finished reading it one phase ago)
+        const int q = sl + 3;
+        if (q < np) stage5((gk + 3) & 3, rAc, rBc, q * 32);
+        else if (has_next) stage5((gk + 3) & 3, rAn, rBn, (q - np) * 32);
+        // slab sl+1 must have landed; the two newer slabs (16 instructions) may stay in flight.  At the tail of
+        // the last tile nothing newer follows.
+        if (!has_next && q >= np) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      }
+      WG_BARRIER_LDS();
+      // ---- COMPUTE
+      if (sl == np - 1 && p.bias) {           // out = alpha * (acc + bias / alpha): no bias registers, no load in the epilogue
+        const float ia = __builtin_amdgcn_rcpf(p.alpha);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 b4 = *(const float4*)(cb + (wn * 64 + ni * 32 + 8 * q + 4 * hi) * 4);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+              acc[ni][mi][4 * q + 0] += b4.x * ia;
+              acc[ni][mi][4 * q + 1] += b4.y * ia;
+              acc[ni][mi][4 * q + 2] += b4.z * ia;
+              acc[ni][mi][4 * q + 3] += b4.w * ia;
+            }
+          }
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][ni], fa[ks][mi], acc[ni][mi], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      WG_BARRIER_LDS();
+    }
+
+    // ---- epilogue.  Window of pass p: W1 (the half-slot the last slab was read from), C window, W1, C window -
+    // the last pass sits in the C window, so the next tile's first DMA (into W1) cannot run into its copy.
+    //   group 0:  write 0 | B0 | write 1 | B1 |                  | B2 |                  | B3 |
+    //   group 1:  (MFMA)  | B0 | copy 0  | B1 | write 2, copy 1  | B2 | write 3, copy 2  | B3 | copy 3
+    char* w1 = smem + ((gk + 3) & 3) * HS_BYTES;
+    int te = tid;
+    asm volatile("" : "+v"(te));     // keep the epilogue's address arithmetic out of the main loop's live range
+    const int l31e = te & 31, hie = (te >> 5) & 1;
+    auto write_pass = [&](int pass, char* win) {     // rows [64*pass, +64) of the tile, MFMA fragment layout -> window
+#pragma unroll
+      for (int mi2 = 0; mi2 < 2; ++mi2) {
+        const int mi = 2 * (pass & 1) + mi2;
+        const int row = mi2 * 32 + l31e;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int nl = wn * 64 + ni * 32 + 8 * q + 4 * hie;
+            u32x2 w;
+            w[0] = pack2bf(acc[ni][mi][4 * q + 0] * p.alpha, acc[ni][mi][4 * q + 1] * p.alpha);
+            w[1] = pack2bf(acc[ni][mi][4 * q + 2] * p.alpha, acc[ni][mi][4 * q + 3] * p.alpha);
+            *(u32x2*)(win + row * 512 + ((((nl >> 3) ^ row) & 31) << 4) + (nl & 7) * 2) = w;
+          }
+      }
+    };
+    auto copy_pass = [&](int pass, const char* win) {   // group 1: 256 threads x 8 chunks = 64 rows x 32 chunks of 16 B
+      const int t = te - 256;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        u32x4 cv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = (half * 4 + j) * 256 + t;
+          const int row = c >> 5, cc = c & 31;
+          cv[j] = *(const u32x4*)(win + row * 512 + (((cc ^ row) & 31) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = (half * 4 + j) * 256 + t;
+          const int row = c >> 5, cc = c & 31;
+          const int m = m0 + pass * 64 + row, n = n0 + cc * 8;
+          const int ms = (p.abl & 32) ? (m & 255) : m;   // ablation 32: every tile's rows alias 256 rows (stores stay in L2)
+          if (m < p.M && n < p.N && !(p.abl & 1)) *(u32x4*)(p.C + ((size_t)ms * p.ldc + n) * 2) = cv[j];
+        }
+      }
+    };
+    if (p.abl & 2) {          // ablation: no epilogue (barrier pattern kept)
+      float t = 0.f;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t += acc[ni][mi][r];
+      if (t == 1.2345e-30f) ((float*)p.C)[tid] = t;
+      if (wm == 0) WG_BARRIER_LDS();
+    } else if (wm == 0) {
+      write_pass(0, w1);
+      WG_BARRIER_LDS();
+      write_pass(1, cb);
+      WG_BARRIER_LDS();
+      WG_BARRIER_LDS();
+      WG_BARRIER_LDS();
+    } else {
+      copy_pass(0, w1);
+      WG_BARRIER_LDS();
+      write_pass(2, w1);
+      copy_pass(1, cb);
+      WG_BARRIER_LDS();
+      write_pass(3, cb);
+      copy_pass(2, w1);
+      WG_BARRIER_LDS();
+      copy_pass(3, cb);
+    }
+    if (!has_next) break;
+    it += gx;
+    m0 = m1;
+    n0 = n1;
+  }
+}
 #undef WG_BARRIER_LDS
 
 // ------------------------------------------------------------------------------------------------
@@ -1078,6 +1307,8 @@ int ensure_attrs() {
     e = hipFuncSetAttribute(v3[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES);
     if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_nt3): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
   }
+  e = hipFuncSetAttribute((const void*)gemm_nt5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES);
+  if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_nt5): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cu = prop.multiProcessorCount;
@@ -1119,7 +1350,13 @@ extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, co
   // 6: role split for every epilogue (experiments).
   // 7: staggered two-group main loop ("nt4") for every bf16-output GEMM; 8: nt4 for the fused epilogues, role
   // split for plain ones.
-  if ((g_nt_variant == 7 || (g_nt_variant == 8 && epi != CLIPA_EPI_NONE)) && !out_f32 && K >= 96) {
+  // 9: v5 (ping-pong + wave roles) for plain / bias epilogues, ping-pong v2 for the fused ones.
+  if (g_nt_variant == 9 && epi == CLIPA_EPI_NONE && !out_f32 && K >= 128) {
+    const unsigned grid = (unsigned)(tiles < g_num_cu ? tiles : g_num_cu);
+    hipLaunchKernelGGL(gemm_nt5_kernel, dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
+    return clipa_check_launch("gemm_nt5");
+  }
+  if ((g_nt_variant == 7 || g_nt_variant == 9 || (g_nt_variant == 8 && epi != CLIPA_EPI_NONE)) && !out_f32 && K >= 96) {
     const unsigned grid = (unsigned)(tiles < g_num_cu ? tiles : g_num_cu);
     hipLaunchKernelGGL((gemm_nt2_kernel<false, true, true>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
     return clipa_check_launch("gemm_nt4");

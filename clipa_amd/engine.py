@@ -60,8 +60,10 @@ def _like_param(g, p):
 # ---------------------------------------------------------------------------------------------
 def _block_forward(x, P, cfg, keep):
     """x [M,D] bf16. P: dict of operand tensors. Returns y and (if keep) the intermediates.
-    keep: False (nothing), True / "full" (everything the backward reads) or "light" (only the GEMM / attention
-    outputs qkv, a, stats, x1, hpre - LayerNorm outputs and the activation are re-materialised in backward)."""
+    keep: False (nothing), True / "full" (everything the backward reads), "light" (only the GEMM / attention
+    outputs qkv, a, stats, x1, hpre - LayerNorm outputs and the activation are re-materialised in backward) or
+    "medium" (light without hpre, 10 instead of 18 bytes per element of x: backward re-runs LN2 + the c_fc GEMM,
+    a third of the block's forward FLOPs, and skips the other three GEMMs and attention)."""
     B, L, H, causal, act = cfg["B"], cfg["L"], cfg["H"], cfg["causal"], cfg["act"]
     h1 = ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"])
     qkv = ops.gemm_nt(h1, P["w_in"], P["b_in"])
@@ -71,12 +73,12 @@ def _block_forward(x, P, cfg, keep):
         a, stats = ops.attention_fwd(qkv, B, L, H, causal), None
     x1 = ops.gemm_nt(a, P["w_out"], P["b_out"], epi=ops.EPI_ADD, aux=x)
     h2 = ops.layernorm_fwd(x1, P["ln2_w"], P["ln2_b"], cfg["eps"])
-    if keep:
+    if keep and keep != "medium":
         g, hpre = ops.gemm_nt(h2, P["w_fc"], P["b_fc"], epi=ops.EPI_ACT, act=act, want_pre=True)
     else:
         g, hpre = ops.gemm_nt(h2, P["w_fc"], P["b_fc"], epi=ops.EPI_ACT, act=act), None
     y = ops.gemm_nt(g, P["w_proj"], P["b_proj"], epi=ops.EPI_ADD, aux=x1)
-    if keep == "light":
+    if keep in ("light", "medium"):
         return y, (None, qkv, a, stats, x1, None, hpre, None)
     if keep:
         return y, (h1, qkv, a, stats, x1, h2, hpre, g)
@@ -88,7 +90,10 @@ def _block_backward(x, dy, box, P, cfg):
     B, L, H, causal, act = cfg["B"], cfg["L"], cfg["H"], cfg["causal"], cfg["act"]
     h1, qkv, a, stats, x1, h2, hpre, g = box.pop()
     dy = dy.contiguous()
-    if g is None:        # "light" block: cheap HBM-bound re-materialisation instead of 4 GEMMs + attention
+    if hpre is None:     # "medium" block: LN2 + c_fc again (one GEMM instead of four + attention)
+        h2 = ops.layernorm_fwd(x1, P["ln2_w"], P["ln2_b"], cfg["eps"])
+        g, hpre = ops.gemm_nt(h2, P["w_fc"], P["b_fc"], epi=ops.EPI_ACT, act=act, want_pre=True)
+    elif g is None:      # "light" block: cheap HBM-bound re-materialisation instead of 4 GEMMs + attention
         g = ops.activation_fwd(hpre, act)
         h2 = ops.layernorm_fwd(x1, P["ln2_w"], P["ln2_b"], cfg["eps"])
     # y = x1 + c_proj(g)

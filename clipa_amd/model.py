@@ -146,6 +146,9 @@ class Transformer(nn.Module):
         # blocks still keep their GEMM / attention outputs ("light" keep, ~18*D bytes per token) so their
         # backward skips the recompute; 288 GB of HBM usually has room for several blocks' worth.
         self.keep_blocks = 0
+        # ... and the next `medium_blocks` blocks keep the same set minus the MLP pre-activation (~10*D bytes per
+        # token) and re-run only LN2 + c_fc in backward.
+        self.medium_blocks = 0
         self.resblocks = nn.ModuleList([_ResBlockParams(width, heads, mlp_ratio) for _ in range(layers)])
 
     def get_cast_dtype(self):
@@ -154,14 +157,18 @@ class Transformer(nn.Module):
     def run(self, x, B, L, causal, cache):
         base = {"B": B, "L": L, "H": self.heads, "causal": bool(causal), "act": self.act, "eps": 1e-5,
                 "recompute": bool(self.grad_checkpointing), "keep": "light"}
-        kept = dict(base, keep_this=True)
+        kept, medium = dict(base, keep_this=True), dict(base, keep_this=True, keep="medium")
         for i, blk in enumerate(self.resblocks):
-            x = engine.ResBlockFn.apply(x, kept if i < self.keep_blocks else base, cache, *blk.param_tuple())
+            cfg = kept if i < self.keep_blocks else (medium if i < self.keep_blocks + self.medium_blocks else base)
+            x = engine.ResBlockFn.apply(x, cfg, cache, *blk.param_tuple())
         return x
 
     def light_keep_bytes(self, tokens):
         """HBM bytes one kept block holds between forward and backward for `tokens` rows."""
         return tokens * 9 * self.width * 2 + tokens * self.heads * 8   # qkv, a, x1, hpre (bf16) + softmax stats
+
+    def medium_keep_bytes(self, tokens):
+        return tokens * 5 * self.width * 2 + tokens * self.heads * 8   # qkv, a, x1 (bf16) + softmax stats
 
 
 class VisionTransformer(nn.Module):

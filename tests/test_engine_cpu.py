@@ -23,12 +23,15 @@ def _swap_ops(monkeypatch):
         monkeypatch.setattr(mod, "ops", cpu_ops)
 
 
-def _run(g, recompute=True, precision="fp32"):
+def _run(g, recompute=True, precision="fp32", tiers=None):
     m = clipa_amd.CLIP(**g.cfg, output_dict=True)
     m.load_state_dict(g.sd, strict=True)
     if precision == "bf16":
         clipa_amd.convert_weights_to_lp(m, torch.bfloat16)
     m.set_grad_checkpointing(recompute)
+    if tiers:
+        for t in (m.visual.transformer, m.transformer):
+            t.keep_blocks, t.medium_blocks = tiers
     out = m(g.images_u8, g.texts)
     loss = clipa_amd.ClipLoss()(**out, output_dict=True)["contrastive_loss"]
     loss.backward()
@@ -60,10 +63,12 @@ def test_engine_orchestration_matches_reference_golden(golden):
 def test_recompute_equals_stored(golden):
     ma, _, la = _run(golden, recompute=True)
     mb, _, lb = _run(golden, recompute=False)
-    assert float(la) == float(lb)
-    for (k, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
+    mc, _, lc = _run(golden, recompute=True, tiers=(1, 1))     # one "light" + one "medium" block per tower
+    assert float(la) == float(lb) == float(lc)
+    for (k, p), (_, q), (_, r) in zip(ma.named_parameters(), mb.named_parameters(), mc.named_parameters()):
         if p.grad is not None:
             assert torch.equal(p.grad, q.grad), k
+            assert torch.equal(p.grad, r.grad), k
 
 
 def test_bf16_precision_mode_and_frozen_tower(golden):

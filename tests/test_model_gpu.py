@@ -94,13 +94,17 @@ def test_all_parameter_gradients_match_oracle(golden):
 def test_recompute_equals_stored_activations(golden):
     g = golden
     ga = {}
-    for rc in (True, False):
-        m = _engine(g, recompute=rc)
+    for rc in (True, False, "mixed"):
+        m = _engine(g, recompute=bool(rc))
+        if rc == "mixed":            # one "light" block, one "medium" block, the rest (if any) fully recomputed
+            for t in (m.visual.transformer, m.transformer):
+                t.keep_blocks, t.medium_blocks = 1, 1
         _, loss = _step(m, g)
         ga[rc] = (float(loss), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
-    assert ga[True][0] == ga[False][0]
+    assert ga[True][0] == ga[False][0] == ga["mixed"][0]
     for k in ga[True][1]:
         assert torch.equal(ga[True][1][k], ga[False][1][k]), k
+        assert torch.equal(ga[True][1][k], ga["mixed"][1][k]), k
 
 
 def test_input_formats_agree():
