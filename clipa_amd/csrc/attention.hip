@@ -146,6 +146,14 @@ __device__ __forceinline__ void softmax_rows(f32x16 (&s)[NKT], const AttnArgs& p
   inv = 1.0f / sum;
 }
 
+// load the k-step fragments of one 32-row tile straight from global memory (rows >= L read zeros)
+template <int KS>
+__device__ __forceinline__ void load_frags(const __amdgpu_buffer_rsrc_t rs, long ld, int row, int hi, bf16x8 (&f)[KS]) {
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+    f[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(row * ld * 2 + (2 * ks + hi) * 16), 0, 0));
+}
+
 template <int NKT, int DH>
 __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_fwd_kernel(AttnArgs p) {
   constexpr int LP = NKT * 32, RB = HD<DH>::RB, KS = HD<DH>::KS, DT = HD<DH>::DT;
@@ -163,16 +171,24 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_fwd_kernel(AttnArgs p) 
   const __amdgpu_buffer_rsrc_t rsV = make_rsrc(p.v + hoff, nrec);
   dma_image<DH>(rsK, sK, LP, p.ld_qkv, wave, lane);
   dma_image<DH>(rsV, sV, LP, p.ld_qkv, wave, lane);
+  // the wave's first query tile rides along with the K / V DMA; each later tile is fetched while the tile
+  // before it computes, so no query load sits on the critical path
+  // (the one shape whose whole-row softmax already fills the 256-VGPR budget of two workgroups per CU - 9 key
+  // tiles at head dim 64 - keeps the plain load)
+  constexpr bool PREFETCH = !(NKT == 9 && DH == 64);
+  bf16x8 fq[KS], fqn[KS];
+  if (PREFETCH) load_frags<KS>(rsQ, p.ld_qkv, 32 * wave + l31, hi, fqn);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int qt = wave; qt < NKT; qt += 4) {
     const int qg = 32 * qt + l31;
-    bf16x8 fq[KS];
+    if (PREFETCH) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsQ, (unsigned)(qg * p.ld_qkv * 2 + (2 * ks + hi) * 16), 0, 0);
-      fq[ks] = __builtin_bit_cast(bf16x8, t);
+      for (int ks = 0; ks < KS; ++ks) fq[ks] = fqn[ks];
+      if (qt + 4 < NKT) load_frags<KS>(rsQ, p.ld_qkv, qg + 128, hi, fqn);
+    } else {
+      load_frags<KS>(rsQ, p.ld_qkv, qg, hi, fq);
     }
     f32x16 s[NKT];
 #pragma unroll
@@ -215,14 +231,6 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_fwd_kernel(AttnArgs p) 
   }
 }
 
-// load the k-step fragments of one 32-row tile straight from global memory (rows >= L read zeros)
-template <int KS>
-__device__ __forceinline__ void load_frags(const __amdgpu_buffer_rsrc_t rs, long ld, int row, int hi, bf16x8 (&f)[KS]) {
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
-    f[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(row * ld * 2 + (2 * ks + hi) * 16), 0, 0));
-}
-
 // Backward.  Two LDS phases share one 2-image window (so two workgroups fit per CU):
 //   phase 1: K, V images; query-major sweep -> dQ   (q / dO / O rows of the wave's tile come from global)
 //   phase 2: Q, dO images; key-major sweep   -> dK, dV (k / v rows of the wave's tile come from global)
@@ -253,14 +261,19 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
   // ---- phase 1: dQ ------------------------------------------------------------------------------
   dma_image<DH>(rsK, img0, LP, p.ld_qkv, wave, lane);
   dma_image<DH>(rsV, img1, LP, p.ld_qkv, wave, lane);
+  bf16x8 fq[KS], fdo[KS], fo[KS];
+  load_frags<KS>(rsQ, p.ld_qkv, 32 * wave + l31, hi, fq);        // first tile's rows ride along with the DMA
+  load_frags<KS>(rsDO, p.ld_o, 32 * wave + l31, hi, fdo);
+  load_frags<KS>(rsO, p.ld_o, 32 * wave + l31, hi, fo);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int qt = wave; qt < NKT; qt += 4) {
     const int qg = 32 * qt + l31;
-    bf16x8 fq[KS], fdo[KS], fo[KS];
-    load_frags<KS>(rsQ, p.ld_qkv, qg, hi, fq);
-    load_frags<KS>(rsDO, p.ld_o, qg, hi, fdo);
-    load_frags<KS>(rsO, p.ld_o, qg, hi, fo);
+    if (qt != wave) {
+      load_frags<KS>(rsQ, p.ld_qkv, qg, hi, fq);
+      load_frags<KS>(rsDO, p.ld_o, qg, hi, fdo);
+      load_frags<KS>(rsO, p.ld_o, qg, hi, fo);
+    }
     float2 st = make_float2(0.f, 0.f);                 // padded queries: inv = 0 -> P = 0
     if (qg < p.L) st = *(const float2*)(stats + qg * 2);
     float Dq = 0.f;
@@ -318,14 +331,18 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
   // ---- phase 2: dK, dV --------------------------------------------------------------------------
   dma_image<DH>(rsQ, img0, LP, p.ld_qkv, wave, lane);
   dma_image<DH>(rsDO, img1, LP, p.ld_o, wave, lane);
+  bf16x8 fk[KS], fv[KS];
+  load_frags<KS>(rsK, p.ld_qkv, 32 * wave + l31, hi, fk);
+  load_frags<KS>(rsV, p.ld_qkv, 32 * wave + l31, hi, fv);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kt = wave; kt < NKT; kt += 4) {
     const int kg = 32 * kt + l31;
     const int kgc = l31 - 4 * hi;      // causal test inside the diagonal tile: key <= query
-    bf16x8 fk[KS], fv[KS];
-    load_frags<KS>(rsK, p.ld_qkv, kg, hi, fk);
-    load_frags<KS>(rsV, p.ld_qkv, kg, hi, fv);
+    if (kt != wave) {
+      load_frags<KS>(rsK, p.ld_qkv, kg, hi, fk);
+      load_frags<KS>(rsV, p.ld_qkv, kg, hi, fv);
+    }
     f32x16 dk[DT], dv[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)

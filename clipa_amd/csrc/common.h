@@ -53,19 +53,63 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
 // ---- activations (transformer.py:37-40 QuickGELU, nn.GELU erf / tanh) ----------------------
 enum { ACT_GELU_ERF = 0, ACT_GELU_TANH = 1, ACT_QUICK_GELU = 2 };
 
-// erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution)
-__device__ __forceinline__ float fast_erf(float x) {
-  float ax = fabsf(x);
-  float t = __frcp_rn(1.0f + 0.3275911f * ax);
-  float p = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t +
-             0.254829592f) * t;
-  float r = 1.0f - p * __expf(-ax * ax);
-  return copysignf(r, x);
+// erf-GELU on PAIRS of values: the polynomial part compiles to packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32,
+// two elements per VALU slot); only rcp and exp2 stay per element.  q(x) = Phi(-|x|) = 0.5*erfc(|x|/sqrt 2) by
+// Abramowitz-Stegun 7.1.26 / 26.2.17 (|err| <= 0.75e-7, far below bf16 resolution):
+//   q = 0.5 * t*(a1 + t*(a2 + t*(a3 + t*(a4 + t*a5)))) * exp(-x^2/2),  t = 1/(1 + 0.2316419*|x|)
+//   gelu(x)  = x*Phi(x)           = max(x, 0) - |x|*q
+//   gelu'(x) = Phi(x) + x*phi(x)  = (x >= 0 ? 1 - q : q) + x * exp(-x^2/2)/sqrt(2 pi)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_tail2(f32x2 x, f32x2 ax, f32x2& e) {
+  const f32x2 d = ax * 0.2316419f + 1.0f;
+  f32x2 t;
+  t.x = __builtin_amdgcn_rcpf(d.x);
+  t.y = __builtin_amdgcn_rcpf(d.y);
+  const f32x2 u = (x * x) * -0.72134752044448170f;        // -x^2/2 * log2(e)
+  e.x = __builtin_amdgcn_exp2f(u.x);
+  e.y = __builtin_amdgcn_exp2f(u.y);
+  const f32x2 p = ((((0.5307027145f * t - 0.7265760135f) * t + 0.7107068705f) * t - 0.142248368f) * t + 0.127414796f) * t;
+  return p * e;
+}
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float x);
+template <int ACT>
+__device__ __forceinline__ float act_bwd(float x);
+
+template <int ACT>
+__device__ __forceinline__ f32x2 act_fwd2(f32x2 x) {
+  if (ACT == ACT_GELU_ERF) {
+    const f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+    f32x2 e;
+    const f32x2 q = gelu_tail2(x, ax, e);
+    const f32x2 relu = {fmaxf(x.x, 0.f), fmaxf(x.y, 0.f)};
+    return relu - ax * q;
+  }
+  f32x2 r;
+  r.x = act_fwd<ACT>(x.x);
+  r.y = act_fwd<ACT>(x.y);
+  return r;
+}
+template <int ACT>
+__device__ __forceinline__ f32x2 act_bwd2(f32x2 x) {  // d act(x) / dx
+  if (ACT == ACT_GELU_ERF) {
+    const f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+    f32x2 e;
+    const f32x2 q = gelu_tail2(x, ax, e);
+    f32x2 cdf;
+    cdf.x = x.x >= 0.f ? 1.0f - q.x : q.x;
+    cdf.y = x.y >= 0.f ? 1.0f - q.y : q.y;
+    return cdf + x * (e * 0.3989422804014327f);
+  }
+  f32x2 r;
+  r.x = act_bwd<ACT>(x.x);
+  r.y = act_bwd<ACT>(x.y);
+  return r;
 }
 template <int ACT>
 __device__ __forceinline__ float act_fwd(float x) {
   if (ACT == ACT_GELU_ERF) {
-    return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f));
+    return act_fwd2<ACT_GELU_ERF>(f32x2{x, x}).x;
   } else if (ACT == ACT_GELU_TANH) {
     float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
     float e = __expf(2.0f * u);
@@ -78,9 +122,7 @@ __device__ __forceinline__ float act_fwd(float x) {
 template <int ACT>
 __device__ __forceinline__ float act_bwd(float x) {  // d act(x) / dx
   if (ACT == ACT_GELU_ERF) {
-    float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f));
-    float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    return act_bwd2<ACT_GELU_ERF>(f32x2{x, x}).x;
   } else if (ACT == ACT_GELU_TANH) {
     float x2 = x * x;
     float u = 0.7978845608028654f * (x + 0.044715f * x * x2);

@@ -43,10 +43,18 @@ template <int ACT>
 __device__ __forceinline__ void epi_apply(int epi, float* v, const float* a) {
   if (epi == CLIPA_EPI_ACT) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = act_fwd<ACT>(v[i]);
+    for (int i = 0; i < 8; i += 2) {
+      const f32x2 r = act_fwd2<ACT>(f32x2{v[i], v[i + 1]});
+      v[i] = r.x;
+      v[i + 1] = r.y;
+    }
   } else {  // CLIPA_EPI_DACT
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = v[i] * act_bwd<ACT>(a[i]);
+    for (int i = 0; i < 8; i += 2) {
+      const f32x2 r = f32x2{v[i], v[i + 1]} * act_bwd2<ACT>(f32x2{a[i], a[i + 1]});
+      v[i] = r.x;
+      v[i + 1] = r.y;
+    }
   }
 }
 
@@ -1263,6 +1271,170 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TNArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm_tn v2: the same product with the PING-PONG schedule of gemm_nt v5.  The reduction axis is walked in
+// slabs of 32 rows (P [32][256] + Q [32][256] = one 32 KiB half-slot, ring of four, three slabs in flight,
+// counted vmcnt(8)); every wave alternates LOAD (24 ds_read_b64_tr_b16 = both k-steps of a slab, its 4 DMA
+// pieces of slab s+3) and COMPUTE (16 MFMAs from registers) with an s_barrier after each, and waves 4-7 run
+// one barrier behind waves 0-3, so each SIMD always has one wave in its MFMA block beside the other wave's
+// LDS phase.  There are no stores in the loop, so every wave can feed the DMA ring.
+#define TN_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+__global__ __launch_bounds__(NTHREADS) void gemm_tn2_kernel(TNArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wr = wave >> 2, wc = wave & 3;   // wave tile: 128 (r) x 64 (c)
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+  const int tilesC = (p.C + 255) / 256;
+  const int tilesR = (p.R + 255) / 256;
+  const unsigned t = xcd_remap(blockIdx.x, (unsigned)(tilesR * tilesC));
+  const int tr = t / tilesC, tc = t - tr * tilesC;
+  const int r0 = tr * 256, c0 = tc * 256;
+  const int slice = blockIdx.y;
+  const long mbeg = (long)slice * p.slice_rows;
+  const long mend = min((long)p.M, mbeg + p.slice_rows);
+  float* O = p.O + (size_t)slice * p.R * p.ldo;
+
+  const long rows_left = p.M - mbeg;
+  auto nrec = [&](long ld, int col0) -> unsigned {
+    long b = rows_left * ld * 2 - (long)col0 * 2;
+    if (b < 0) b = 0;
+    return (unsigned)(b > 0xffffffffL ? 0xffffffffL : b);
+  };
+  const u32x4 rsP = make_srd(p.P + ((size_t)mbeg * p.ldp + r0) * 2, nrec(p.ldp, r0));
+  const u32x4 rsQ = make_srd(p.Q + ((size_t)mbeg * p.ldq + c0) * 2, nrec(p.ldq, c0));
+
+  // DMA piece pc (1 KiB) = slab rows 2pc, 2pc+1 (512 B each); wave w moves pieces w and w+8 of P and of Q
+  unsigned voffP[2], voffQ[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (j * 8 + wave) * 2 + (lane >> 5);
+    const int chunk = (lane & 31) ^ tn_swz(row);
+    voffP[j] = (unsigned)(row * p.ldp * 2 + chunk * 16);
+    voffQ[j] = (unsigned)(row * p.ldq * 2 + chunk * 16);
+  }
+  auto stage = [&](unsigned slot, long mrow) {   // mrow relative to mbeg
+    const unsigned d = lds0 + slot * HS_BYTES + wave * 1024;
+    const unsigned soffP = (unsigned)(mrow * p.ldp * 2), soffQ = (unsigned)(mrow * p.ldq * 2);
+    dma16(rsP, d, voffP[0], soffP);
+    dma16(rsP, d + 8192, voffP[1], soffP);
+    dma16(rsQ, d + 16384, voffQ[0], soffQ);
+    dma16(rsQ, d + 16384 + 8192, voffQ[1], soffQ);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ri][ci][r] = 0.f;
+
+  const int q16 = (lane >> 4) & 1, i16 = lane & 15;
+  const int rsub = 8 * hi + (i16 >> 2);          // + ms*16 + 4*half
+  const int csub = 16 * q16 + 4 * (i16 & 3);     // + colbase (multiple of 32)
+  const bool do_colsum = p.colsum != nullptr && tc == 0;
+  const int cs_ch = tid & 31, cs_rg = tid >> 5;   // 32 column chunks x 16 row groups (2 rows of a slab each)
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  const int nsl = (int)((mend - mbeg + 31) / 32);
+  if (nsl <= 0) {
+    // nothing to reduce in this slice: the slab is still defined (zeros) because the reduce kernel sums every slice
+  } else {
+    for (int s0 = 0; s0 < 3 && s0 < nsl; ++s0) stage(s0, (long)s0 * 32);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  TN_BARRIER();
+  if (wr == 1) TN_BARRIER();                 // waves 4-7 run one barrier behind
+  for (int sl = 0; sl < nsl; ++sl) {
+    // ---- LOAD
+    const char* sP = smem + (sl & 3) * HS_BYTES;
+    const char* sQ = sP + 16384;
+    bf16x8 fp[2][4], fq[2][2];
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int row = ms * 16 + 4 * half + rsub;
+        const int swz = tn_swz(row);
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+          const int col = wr * 128 + ri * 32 + csub;
+          const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) bf16x4*)(sP + row * 512 + (((col >> 3) ^ swz) << 4) + (col & 7) * 2));
+          fp[ms][ri][4 * half + 0] = v[0]; fp[ms][ri][4 * half + 1] = v[1];
+          fp[ms][ri][4 * half + 2] = v[2]; fp[ms][ri][4 * half + 3] = v[3];
+        }
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci) {
+          const int col = wc * 64 + ci * 32 + csub;
+          const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) bf16x4*)(sQ + row * 512 + (((col >> 3) ^ swz) << 4) + (col & 7) * 2));
+          fq[ms][ci][4 * half + 0] = v[0]; fq[ms][ci][4 * half + 1] = v[1];
+          fq[ms][ci][4 * half + 2] = v[2]; fq[ms][ci][4 * half + 3] = v[3];
+        }
+      }
+    if (do_colsum) {
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int row = cs_rg * 2 + rr;
+        float f[8];
+        unpack8(*(const u32x4*)(sP + row * 512 + ((cs_ch ^ tn_swz(row)) << 4)), f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) csum[i] += f[i];
+      }
+    }
+    if (sl + 3 < nsl) {
+      stage((unsigned)((sl + 3) & 3), (long)(sl + 3) * 32);   // into the half-slot of slab sl-1
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // slab sl+1 landed; sl+2, sl+3 may be in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    TN_BARRIER();
+    // ---- COMPUTE
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+      for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+          acc[ri][ci] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fp[ms][ri], fq[ms][ci], acc[ri][ci], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    TN_BARRIER();
+  }
+  if (wr == 0) TN_BARRIER();
+
+#pragma unroll
+  for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+      const int c = c0 + wc * 64 + ci * 32 + l31;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int r = r0 + wr * 128 + ri * 32 + 8 * (reg >> 2) + 4 * hi + (reg & 3);
+        if (r < p.R && c < p.C) O[(size_t)r * p.ldo + c] = acc[ri][ci][reg];
+      }
+    }
+  if (do_colsum) {
+    __syncthreads();
+    float* red = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[cs_rg * 256 + cs_ch * 8 + i] = csum[i];
+    __syncthreads();
+    if (tid < 256) {
+      float a = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) a += red[g * 256 + tid];
+      if (r0 + tid < p.R) p.colsum[(size_t)slice * p.R + r0 + tid] = a;
+    }
+  }
+}
+#undef TN_BARRIER
+
 // out[i] = cast(sum_s slab[s][i]); out dtype bf16 or f32
 template <bool OUT_BF16>
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, void* __restrict__ out, long n, int S) {
@@ -1292,6 +1464,8 @@ int ensure_attrs() {
   if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_nt<bf16>): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
   e = hipFuncSetAttribute((const void*)gemm_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_nt<f32>): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
+  e = hipFuncSetAttribute((const void*)gemm_tn2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+  if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_tn2): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
   e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
   if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_tn): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
   const void* v2[5] = {(const void*)gemm_nt2_kernel<false, false>, (const void*)gemm_nt2_kernel<false, true>,
@@ -1412,7 +1586,9 @@ extern "C" int clipa_gemm_tn(const void* P, const void* Q, void* out, float* col
   a.M = (int)M; a.R = (int)R; a.C = (int)C; a.ldp = ldp; a.ldq = ldq; a.ldo = C; a.slice_rows = (int)slice_rows;
   a.colsum = colsum_out ? (float*)workspace + S * R * C : nullptr;
   const long tiles = ((R + 255) / 256) * ((C + 255) / 256);
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)tiles, (unsigned)S), dim3(NTHREADS), 2 * STAGE_BYTES, (hipStream_t)stream, a);
+  // ablation bit 9 (512) selects the first-generation kernel (one barrier per 64 rows, all waves in step)
+  if (g_abl & 512) hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)tiles, (unsigned)S), dim3(NTHREADS), 2 * STAGE_BYTES, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(gemm_tn2_kernel, dim3((unsigned)tiles, (unsigned)S), dim3(NTHREADS), 2 * STAGE_BYTES, (hipStream_t)stream, a);
   if (int rc = clipa_check_launch("gemm_tn")) return rc;
   const long n = R * C;
   const unsigned blocks = (unsigned)((n / 4 + 255) / 256);

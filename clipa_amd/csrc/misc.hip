@@ -591,7 +591,11 @@ __global__ void activation_kernel(const unsigned short* __restrict__ in, unsigne
     float f[8];
     unpack8(*(const u32x4*)(in + i * 8), f);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) f[k] = act_fwd<ACT>(f[k]);
+    for (int k = 0; k < 8; k += 2) {
+      const f32x2 r = act_fwd2<ACT>(f32x2{f[k], f[k + 1]});
+      f[k] = r.x;
+      f[k + 1] = r.y;
+    }
     *(u32x4*)(out + i * 8) = pack8(f);
   }
 }

@@ -15,10 +15,10 @@ pytestmark = pytest.mark.gpu
 B_LOC, S, CTX = 8, 112, 32
 
 
-def _build(dev):
+def _build(dev, precision="amp_bf16"):
     import clipa_amd
     torch.manual_seed(0)
-    m = clipa_amd.create_model("ViT-S-16", precision="amp_bf16", device=dev, force_image_size=S, output_dict=True)
+    m = clipa_amd.create_model("ViT-S-16", precision=precision, device=dev, force_image_size=S, output_dict=True)
     m.positional_embedding = torch.nn.Parameter(m.positional_embedding[:CTX].clone())
     m.set_grad_checkpointing(True)
     m.transformer.keep_blocks = 2          # mix recomputed and kept blocks
@@ -130,8 +130,9 @@ def _rccl_worker(port, q):
     rs = L._reduce_scatter_fused(full, 1)
     torch.cuda.synchronize()
     ok = torch.equal(out, local) and torch.equal(rs, full)
-    # the whole step under DDP on the RCCL backend (world 1: bucket all-reduce is the identity)
-    model = _build(dev)
+    # the whole step under DDP on the RCCL backend (world 1: bucket all-reduce is the identity), pure-bf16
+    # parameters and gradients as in bench.py
+    model = _build(dev, precision="bf16")
     ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], static_graph=True)
     img, txt = _batch(1)
     o = ddp(img.to(dev), txt.to(dev))
