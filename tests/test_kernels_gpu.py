@@ -86,6 +86,51 @@ def test_gemm_nt_epilogues(act):
     check("act backward", out, v * x.grad, 2 ** -6, 6e-3)
 
 
+def _debug_set(variant, abl):
+    import ctypes
+    from clipa_amd import lib
+    h = lib.load()
+    h.clipa_debug_set.argtypes = [ctypes.c_int, ctypes.c_int]
+    assert h.clipa_debug_set(variant, abl) == 0
+
+
+@pytest.mark.parametrize("variant", [1, 2, 5, 7, 9])
+def test_gemm_nt_kernel_generations_agree(variant):
+    """Every gemm_nt generation kept for A/B runs (one tile per workgroup, persistent, loader/storer roles,
+    ping-pong, ping-pong + roles) computes the same thing on ragged shapes and with every epilogue."""
+    o = ops()
+    try:
+        for (M, N, K) in [(300, 264, 136), (1000, 520, 776), (777, 1024, 768), (2048, 256, 4096)]:
+            a, b = rnd(M, K, seed=M), rnd(N, K, seed=N, scale=0.05)
+            bias, aux = rnd(N, seed=3, dtype=f32), rnd(M, N, seed=4)
+            ad, bd, biasd, auxd = a.to(DEV), b.to(DEV), bias.to(DEV), aux.to(DEV)
+            lin = a.double() @ b.double().T + bias.double()
+            for rep in range(2):           # second launch: ring state carried between tiles / launches
+                _debug_set(variant, 0)
+                check("bias", o.gemm_nt(ad, bd, biasd), lin, 2 ** -7, 2e-3)
+                check("residual", o.gemm_nt(ad, bd, biasd, epi=o.EPI_ADD, aux=auxd), lin + aux.double(), 2 ** -6, 2e-2)   # two bf16 roundings
+                g, pre = o.gemm_nt(ad, bd, biasd, epi=o.EPI_ACT, act=0, want_pre=True)
+                check("pre", pre, lin, 2 ** -7, 2e-3)
+                check("gelu", g, ref_act(pre.double().cpu(), 0), 2 ** -7, 2e-3)
+    finally:
+        _debug_set(5, 0)
+
+
+def test_gemm_tn_kernel_generations_agree():
+    """The ping-pong weight-gradient kernel reduces in the same order as the first generation: bit-identical."""
+    o = ops()
+    p, q = rnd(70000, 520, seed=13).to(DEV), rnd(70000, 264, seed=14, scale=0.1).to(DEV)
+    try:
+        _debug_set(5, 0)
+        w2, c2 = o.gemm_tn(p, q, bf16, want_colsum=True)
+        _debug_set(5, 512)
+        w1, c1 = o.gemm_tn(p, q, bf16, want_colsum=True)
+    finally:
+        _debug_set(5, 0)
+    assert torch.equal(w1, w2)
+    check("column sums", c2, c1, 1e-6, 1e-4)
+
+
 @pytest.mark.parametrize("M,R,C", [(64, 256, 256), (1000, 264, 136), (4100, 1024, 512), (130, 8, 2304), (8, 16, 16)])
 def test_gemm_tn(M, R, C):
     p, q = rnd(M, R, seed=10), rnd(M, C, seed=11, scale=0.1)
