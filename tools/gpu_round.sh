@@ -42,7 +42,7 @@ for s in $STAGES; do
       R="$PWD"
       for set in "FETCH_SIZE" "WRITE_SIZE"; do
         (cd /tmp && timeout 600 rocprofv3 --pmc $set -d "$R/gpurun_out/pmcbench/$set" -o pmc -- \
-           python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --keep-blocks 12,0 > "$R/gpurun_out/pmcbench/$set.log" 2>&1)
+           python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --keep-blocks 0,0,23,2 > "$R/gpurun_out/pmcbench/$set.log" 2>&1)
       done
       python tools/pmc_summary.py gpurun_out/pmcbench gemm attn > gpurun_out/pmcbench_summary.txt 2>&1 ;;
     prof)
