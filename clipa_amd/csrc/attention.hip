@@ -113,16 +113,17 @@ __device__ __forceinline__ void store_frag_T(char* base, long ld, long row, int 
 // Row softmax over the transposed score fragments of one 32-query tile.  In: raw q.k scores.  Out: s =
 // exp2(c*(s - rowmax)) (un-normalised, c = scale*log2 e folded into one FMA), inv = 1/rowsum, m2 = c*rowmax.
 // key(kt, r) = 32kt + 8(r>>2) + (r&3) + 4hi is valid iff < lim (padding / causal bound); tiles valid for
-// every lane (wave-uniform test) skip the compare/select.
-template <int NKT>
+// every lane skip the compare/select: without a causal mask only the last key tile can be partial (NKT =
+// ceil(L / 32) exactly), so the image tower pays 16 compares per row instead of 16 * NKT.
+template <int NKT, bool CAUSAL>
 __device__ __forceinline__ void softmax_rows(f32x16 (&s)[NKT], const AttnArgs& p, int qt, int qg, int hi,
                                              float& inv, float& m2) {
   const float c = p.scale * 1.4426950408889634f;
-  const int lim2 = (p.causal ? min(p.L, qg + 1) : p.L) - 4 * hi;
+  const int lim2 = (CAUSAL ? min(p.L, qg + 1) : p.L) - 4 * hi;
   float mx = -1e30f;
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) {
-    const bool full = (32 * kt + 32 <= p.L) && (!p.causal || kt < qt);
+    const bool full = CAUSAL ? ((32 * kt + 32 <= p.L) && kt < qt) : (kt < NKT - 1);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float v = s[kt][r];
@@ -154,7 +155,7 @@ __device__ __forceinline__ void load_frags(const __amdgpu_buffer_rsrc_t rs, long
     f[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(row * ld * 2 + (2 * ks + hi) * 16), 0, 0));
 }
 
-template <int NKT, int DH>
+template <int NKT, int DH, bool CAUSAL>
 __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_fwd_kernel(AttnArgs p) {
   constexpr int LP = NKT * 32, RB = HD<DH>::RB, KS = HD<DH>::KS, DT = HD<DH>::DT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -195,13 +196,14 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_fwd_kernel(AttnArgs p) 
     for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-      if (p.causal && kt > qt) continue;
+      if (CAUSAL && kt > qt) continue;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
         s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct<DH>(sK, 32 * kt, l31, hi, ks), fq[ks], s[kt], 0, 0, 0);
+      if (!CAUSAL && (kt & 1)) __builtin_amdgcn_sched_barrier(0);   // keep the K-fragment reads of later tiles from piling up in registers
     }
     float inv, m2;
-    softmax_rows<NKT>(s, p, qt, qg, hi, inv, m2);
+    softmax_rows<NKT, CAUSAL>(s, p, qt, qg, hi, inv, m2);
 
     f32x16 o[DT];
 #pragma unroll
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_fwd_kernel(AttnArgs p) 
       for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      if (p.causal && kt > qt) continue;
+      if (CAUSAL && kt > qt) continue;
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         float pv[8];
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_fwd_kernel(AttnArgs p) 
 //   phase 1: K, V images; query-major sweep -> dQ   (q / dO / O rows of the wave's tile come from global)
 //   phase 2: Q, dO images; key-major sweep   -> dK, dV (k / v rows of the wave's tile come from global)
 // Probabilities are recomputed from the forward's (c*rowmax, 1/rowsum) statistics; D_q = <dO_q, O_q>.
-template <int NKT, int DH>
+template <int NKT, int DH, bool CAUSAL>
 __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) {
   constexpr int LP = NKT * 32, RB = HD<DH>::RB, KS = HD<DH>::KS, DT = HD<DH>::DT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
     }
     Dq += __shfl_xor(Dq, 32, 64);
     if (hi == 0) { sM[qg] = st.x; sL[qg] = st.y; sD[qg] = Dq; }
-    const int lim2 = (p.causal ? min(p.L, qg + 1) : p.L) - 4 * hi;
+    const int lim2 = (CAUSAL ? min(p.L, qg + 1) : p.L) - 4 * hi;
     f32x16 dq[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
       for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      if (p.causal && kt > qt) continue;
+      if (CAUSAL && kt > qt) continue;
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct<DH>(img0, 32 * kt, l31, hi, ks), fq[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct<DH>(img1, 32 * kt, l31, hi, ks), fdo[ks], dp, 0, 0, 0);
       }
-      const bool full = (32 * kt + 32 <= p.L) && (!p.causal || kt < qt);
+      const bool full = CAUSAL ? ((32 * kt + 32 <= p.L) && kt < qt) : (kt < NKT - 1);
       float ds[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
-    for (int qt = (p.causal ? kt : 0); qt < NKT; ++qt) {
+    for (int qt = (CAUSAL ? kt : 0); qt < NKT; ++qt) {
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
           // query = 32qt + 8rq + e + 4hi.  Padded queries carry inv = 0; padded keys need no mask: their
           // K/V rows are zero, their column is never stored and never mixes into other lanes' columns.
           float pe = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mm[e])) * ll[e];
-          if (p.causal && qt == kt) pe = (kgc <= 8 * rq + e) ? pe : 0.f;
+          if (CAUSAL && qt == kt) pe = (kgc <= 8 * rq + e) ? pe : 0.f;
           pr[r] = pe;
           ds[r] = pe * (dp[r] - dd[e]) * p.scale;
         }
@@ -399,29 +401,37 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
   }
 }
 
-template <int NKT, int DH>
-int launch_fwd(const AttnArgs& a, hipStream_t st) {
+template <int NKT, int DH, bool CAUSAL>
+int launch_fwd_c(const AttnArgs& a, hipStream_t st) {
   const int lds = 2 * NKT * 32 * HD<DH>::RB;
   static bool done = false;
   if (!done) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NKT, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NKT, DH, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { clipa_set_error("attn_fwd attr: %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
     done = true;
   }
-  hipLaunchKernelGGL((attn_fwd_kernel<NKT, DH>), dim3((unsigned)(a.B * a.H)), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((attn_fwd_kernel<NKT, DH, CAUSAL>), dim3((unsigned)(a.B * a.H)), dim3(256), lds, st, a);
   return clipa_check_launch("attn_fwd");
 }
 template <int NKT, int DH>
-int launch_bwd(const AttnArgs& a, hipStream_t st) {
+int launch_fwd(const AttnArgs& a, hipStream_t st) {
+  return a.causal ? launch_fwd_c<NKT, DH, true>(a, st) : launch_fwd_c<NKT, DH, false>(a, st);
+}
+template <int NKT, int DH, bool CAUSAL>
+int launch_bwd_c(const AttnArgs& a, hipStream_t st) {
   const int lds = 2 * NKT * 32 * HD<DH>::RB + 3 * NKT * 32 * 4;
   static bool done = false;
   if (!done) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NKT, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NKT, DH, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { clipa_set_error("attn_bwd attr: %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
     done = true;
   }
-  hipLaunchKernelGGL((attn_bwd_kernel<NKT, DH>), dim3((unsigned)(a.B * a.H)), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((attn_bwd_kernel<NKT, DH, CAUSAL>), dim3((unsigned)(a.B * a.H)), dim3(256), lds, st, a);
   return clipa_check_launch("attn_bwd");
+}
+template <int NKT, int DH>
+int launch_bwd(const AttnArgs& a, hipStream_t st) {
+  return a.causal ? launch_bwd_c<NKT, DH, true>(a, st) : launch_bwd_c<NKT, DH, false>(a, st);
 }
 
 int check_args(int64_t B, int64_t H, int64_t L, int64_t dh, int64_t ld_qkv, int64_t ld_o) {
