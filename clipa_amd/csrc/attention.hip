@@ -42,6 +42,13 @@ struct HD {
   static constexpr int DT = (DH + 31) / 32;         // 32-wide output tiles over the head dim
   static constexpr int WGS = DH == 64 ? 2 : 1;      // workgroups per CU the LDS image allows
 };
+// Short sequences (CLIPA's 84-112 px images = 26-50 tokens, 8-32 token captions) fit one or two 32-row tiles: a
+// workgroup then takes 4 or 2 heads (one or two waves each) instead of idling three or two of its waves.
+template <int NKT>
+struct WGHeads {
+  static constexpr int HPW = NKT == 1 ? 4 : (NKT == 2 ? 2 : 1);   // heads per workgroup
+  static constexpr int WPH = 4 / HPW;                             // waves per head
+};
 
 // chunk permutation of an LDS row: conflict-free for both the direct ds_read_b128 operand reads and the
 // transposed ds_read_b64_tr_b16 reads (tools/lds_bank_sim.py) - 8 chunks per 128-B row, 16 per 256-B row
@@ -54,9 +61,9 @@ __device__ __forceinline__ int swz_u(int row) {
 // DMA rows [0, LP) of one head into a swizzled LDS image; rows >= L and chunks >= dh read zeros
 template <int DH>
 __device__ __forceinline__ void dma_image(const __amdgpu_buffer_rsrc_t rs, char* img, int LP, long ld,
-                                          int wave, int lane) {
+                                          int wave, int lane, int nwaves = 4) {
   constexpr int NCH = HD<DH>::NCH, RPP = 1024 / HD<DH>::RB;
-  for (int pc = wave; pc < LP / RPP; pc += 4) {
+  for (int pc = wave; pc < LP / RPP; pc += nwaves) {
     const int row = pc * RPP + lane / NCH;
     const int chunk = (lane & (NCH - 1)) ^ swz_u<DH>(row);
     const unsigned oob = (chunk * 8 >= DH) ? 0x80000000u : 0u;
@@ -159,19 +166,25 @@ template <int NKT, int DH, bool CAUSAL>
 __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_fwd_kernel(AttnArgs p) {
   constexpr int LP = NKT * 32, RB = HD<DH>::RB, KS = HD<DH>::KS, DT = HD<DH>::DT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sK = smem;
-  char* sV = smem + LP * RB;
+  constexpr int HPW = WGHeads<NKT>::HPW, WPH = WGHeads<NKT>::WPH;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_wg = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slot = wave_wg / WPH, wave = wave_wg % WPH;          // head slot of this wave, wave index within the head
+  char* sK = smem + slot * (2 * LP * RB);
+  char* sV = sK + LP * RB;
   const int l31 = lane & 31, hi = lane >> 5, q16 = (lane >> 4) & 1, i16 = lane & 15;
-  const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+  const long nheads = (long)p.B * p.H;
+  const long head_raw = (long)blockIdx.x * HPW + slot;
+  const bool live = head_raw < nheads;                           // the last workgroup may have empty head slots
+  const long head = live ? head_raw : nheads - 1;
+  const int b = (int)(head / p.H), h = (int)(head - (long)b * p.H);
   const size_t hoff = ((size_t)b * p.L * p.ld_qkv + (size_t)h * DH) * 2;
   const unsigned nrec = (unsigned)((long)(p.L - 1) * p.ld_qkv * 2 + DH * 2);
   const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.q + hoff, nrec);
   const __amdgpu_buffer_rsrc_t rsK = make_rsrc(p.k + hoff, nrec);
   const __amdgpu_buffer_rsrc_t rsV = make_rsrc(p.v + hoff, nrec);
-  dma_image<DH>(rsK, sK, LP, p.ld_qkv, wave, lane);
-  dma_image<DH>(rsV, sV, LP, p.ld_qkv, wave, lane);
+  dma_image<DH>(rsK, sK, LP, p.ld_qkv, wave, lane, WPH);
+  dma_image<DH>(rsV, sV, LP, p.ld_qkv, wave, lane, WPH);
   // the wave's first query tile rides along with the K / V DMA; each later tile is fetched while the tile
   // before it computes, so no query load sits on the critical path
   // (the one shape whose whole-row softmax already fills the 256-VGPR budget of two workgroups per CU - 9 key
@@ -182,12 +195,12 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_fwd_kernel(AttnArgs p) 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  for (int qt = wave; qt < NKT; qt += 4) {
+  for (int qt = wave; qt < NKT; qt += WPH) {
     const int qg = 32 * qt + l31;
     if (PREFETCH) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) fq[ks] = fqn[ks];
-      if (qt + 4 < NKT) load_frags<KS>(rsQ, p.ld_qkv, qg + 128, hi, fqn);
+      if (qt + WPH < NKT) load_frags<KS>(rsQ, p.ld_qkv, qg + 32 * WPH, hi, fqn);
     } else {
       load_frags<KS>(rsQ, p.ld_qkv, qg, hi, fq);
     }
@@ -224,11 +237,11 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_fwd_kernel(AttnArgs p) 
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans<DH>(sV, 32 * kt + 16 * s2, 32 * dt, hi, q16, i16), pf, o[dt], 0, 0, 0);
       }
     }
-    if (qg < p.L) {
+    if (qg < p.L && live) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
         store_frag_T(p.o, p.ld_o, (long)b * p.L + qg, h * DH + 32 * dt, hi, o[dt], inv, DH - 32 * dt);
-      if (p.stats && hi == 0) *(float2*)(p.stats + ((size_t)blockIdx.x * p.L + qg) * 2) = make_float2(m2, inv);
+      if (p.stats && hi == 0) *(float2*)(p.stats + ((size_t)head * p.L + qg) * 2) = make_float2(m2, inv);
     }
   }
 }
@@ -241,15 +254,21 @@ template <int NKT, int DH, bool CAUSAL>
 __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) {
   constexpr int LP = NKT * 32, RB = HD<DH>::RB, KS = HD<DH>::KS, DT = HD<DH>::DT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* img0 = smem;
-  char* img1 = smem + LP * RB;
-  float* sM = (float*)(smem + 2 * LP * RB);
+  constexpr int HPW = WGHeads<NKT>::HPW, WPH = WGHeads<NKT>::WPH;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_wg = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slot = wave_wg / WPH, wave = wave_wg % WPH;
+  char* img0 = smem + slot * (2 * LP * RB + 3 * LP * 4);
+  char* img1 = img0 + LP * RB;
+  float* sM = (float*)(img0 + 2 * LP * RB);
   float* sL = sM + LP;
   float* sD = sL + LP;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5, q16 = (lane >> 4) & 1, i16 = lane & 15;
-  const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+  const long nheads = (long)p.B * p.H;
+  const long head_raw = (long)blockIdx.x * HPW + slot;
+  const bool live = head_raw < nheads;
+  const long head = live ? head_raw : nheads - 1;
+  const int b = (int)(head / p.H), h = (int)(head - (long)b * p.H);
   const size_t hoff = ((size_t)b * p.L * p.ld_qkv + (size_t)h * DH) * 2;
   const size_t ooff = ((size_t)b * p.L * p.ld_o + (size_t)h * DH) * 2;
   const unsigned nrec = (unsigned)((long)(p.L - 1) * p.ld_qkv * 2 + DH * 2);
@@ -258,18 +277,18 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
                                rsV = make_rsrc(p.v + hoff, nrec), rsDO = make_rsrc(p.d_o + ooff, nrec_o),
                                rsO = make_rsrc(p.o_in + ooff, nrec_o);
   const float c = p.scale * 1.4426950408889634f;
-  const float* stats = p.stats + (size_t)blockIdx.x * p.L * 2;
+  const float* stats = p.stats + (size_t)head * p.L * 2;
 
   // ---- phase 1: dQ ------------------------------------------------------------------------------
-  dma_image<DH>(rsK, img0, LP, p.ld_qkv, wave, lane);
-  dma_image<DH>(rsV, img1, LP, p.ld_qkv, wave, lane);
+  dma_image<DH>(rsK, img0, LP, p.ld_qkv, wave, lane, WPH);
+  dma_image<DH>(rsV, img1, LP, p.ld_qkv, wave, lane, WPH);
   bf16x8 fq[KS], fdo[KS], fo[KS];
   load_frags<KS>(rsQ, p.ld_qkv, 32 * wave + l31, hi, fq);        // first tile's rows ride along with the DMA
   load_frags<KS>(rsDO, p.ld_o, 32 * wave + l31, hi, fdo);
   load_frags<KS>(rsO, p.ld_o, 32 * wave + l31, hi, fo);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int qt = wave; qt < NKT; qt += 4) {
+  for (int qt = wave; qt < NKT; qt += WPH) {
     const int qg = 32 * qt + l31;
     if (qt != wave) {
       load_frags<KS>(rsQ, p.ld_qkv, qg, hi, fq);
@@ -322,7 +341,7 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
           dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans<DH>(img0, 32 * kt + 16 * s2, 32 * dt, hi, q16, i16), dsf, dq[dt], 0, 0, 0);
       }
     }
-    if (qg < p.L) {
+    if (qg < p.L && live) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
         store_frag_T(p.dq, p.ld_dqkv, (long)b * p.L + qg, h * DH + 32 * dt, hi, dq[dt], 1.0f, DH - 32 * dt);
@@ -331,14 +350,14 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
   __syncthreads();   // everyone is done with the K / V images (and the statistics are in LDS)
 
   // ---- phase 2: dK, dV --------------------------------------------------------------------------
-  dma_image<DH>(rsQ, img0, LP, p.ld_qkv, wave, lane);
-  dma_image<DH>(rsDO, img1, LP, p.ld_o, wave, lane);
+  dma_image<DH>(rsQ, img0, LP, p.ld_qkv, wave, lane, WPH);
+  dma_image<DH>(rsDO, img1, LP, p.ld_o, wave, lane, WPH);
   bf16x8 fk[KS], fv[KS];
   load_frags<KS>(rsK, p.ld_qkv, 32 * wave + l31, hi, fk);
   load_frags<KS>(rsV, p.ld_qkv, 32 * wave + l31, hi, fv);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int kt = wave; kt < NKT; kt += 4) {
+  for (int kt = wave; kt < NKT; kt += WPH) {
     const int kg = 32 * kt + l31;
     const int kgc = l31 - 4 * hi;      // causal test inside the diagonal tile: key <= query
     if (kt != wave) {
@@ -391,7 +410,7 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
         }
       }
     }
-    if (kg < p.L) {
+    if (kg < p.L && live) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         store_frag_T(p.dk, p.ld_dqkv, (long)b * p.L + kg, h * DH + 32 * dt, hi, dk[dt], 1.0f, DH - 32 * dt);
@@ -403,14 +422,15 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
 
 template <int NKT, int DH, bool CAUSAL>
 int launch_fwd_c(const AttnArgs& a, hipStream_t st) {
-  const int lds = 2 * NKT * 32 * HD<DH>::RB;
+  constexpr int HPW = WGHeads<NKT>::HPW;
+  const int lds = HPW * 2 * NKT * 32 * HD<DH>::RB;
   static bool done = false;
   if (!done) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NKT, DH, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { clipa_set_error("attn_fwd attr: %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
     done = true;
   }
-  hipLaunchKernelGGL((attn_fwd_kernel<NKT, DH, CAUSAL>), dim3((unsigned)(a.B * a.H)), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((attn_fwd_kernel<NKT, DH, CAUSAL>), dim3((unsigned)(((long)a.B * a.H + HPW - 1) / HPW)), dim3(256), lds, st, a);
   return clipa_check_launch("attn_fwd");
 }
 template <int NKT, int DH>
@@ -419,14 +439,15 @@ int launch_fwd(const AttnArgs& a, hipStream_t st) {
 }
 template <int NKT, int DH, bool CAUSAL>
 int launch_bwd_c(const AttnArgs& a, hipStream_t st) {
-  const int lds = 2 * NKT * 32 * HD<DH>::RB + 3 * NKT * 32 * 4;
+  constexpr int HPW = WGHeads<NKT>::HPW;
+  const int lds = HPW * (2 * NKT * 32 * HD<DH>::RB + 3 * NKT * 32 * 4);
   static bool done = false;
   if (!done) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NKT, DH, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { clipa_set_error("attn_bwd attr: %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
     done = true;
   }
-  hipLaunchKernelGGL((attn_bwd_kernel<NKT, DH, CAUSAL>), dim3((unsigned)(a.B * a.H)), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((attn_bwd_kernel<NKT, DH, CAUSAL>), dim3((unsigned)(((long)a.B * a.H + HPW - 1) / HPW)), dim3(256), lds, st, a);
   return clipa_check_launch("attn_bwd");
 }
 template <int NKT, int DH>
