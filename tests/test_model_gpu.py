@@ -195,3 +195,27 @@ def test_loss_matches_oracle_at_larger_batch():
         a, b = a.double().cpu().reshape(-1), b.double().reshape(-1)
         assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.999
     assert abs(float(sg.grad) - float(sr.grad)) < 2e-2 * abs(float(sr.grad)) + 1e-5
+
+
+def test_full_size_batch_properties():
+    """BASELINE config 3's per-GPU shape (ViT-L/16 @ 224 + text-77, 4096 pairs) in one forward: unit-norm features,
+    per-sample results independent of the batch they ride in, loss = ln(B) at init up to the logit noise."""
+    torch.manual_seed(0)
+    m = clipa_amd.create_model("ViT-L-16", precision="bf16", device=DEV, output_dict=True)
+    B = 4096
+    img, txt = O.synthetic_batch(64, 224, 77, 49408, seed=9)
+    img = img.to(DEV).repeat(B // 64, 1, 1, 1)
+    img += (torch.arange(B, device=DEV) % 251).to(torch.uint8).view(B, 1, 1, 1)      # no two images identical
+    txt = txt.to(DEV).repeat(B // 64, 1)
+    txt[:, 1] = 1 + (torch.arange(B, device=DEV) % 40000)
+    with torch.no_grad():
+        full = m(img, txt)
+        pick = torch.tensor([0, 1, 777, 2048, 4095], device=DEV)
+        small = m(img[pick], txt[pick])
+        loss = clipa_amd.ClipLoss()(full["image_features"], full["text_features"], full["logit_scale"])
+    for k in ("image_features", "text_features"):
+        f = full[k].float()
+        assert torch.isfinite(f).all()
+        assert (f.norm(dim=-1) - 1).abs().max() < 1e-2           # bf16 features
+        assert torch.equal(full[k][pick], small[k]), k           # row-major token matrix: no cross-sample mixing
+    assert abs(float(loss) - math.log(B)) < 0.5
