@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "amp_bf16"],
                     help="bf16 = reference 'bf16' mode (bf16 weights); amp_bf16 = fp32 master weights")
     ap.add_argument("--keep-blocks", default="auto", help="'auto' or 'LV,LT[,MV,MT]': light-kept (and medium-kept) blocks per tower (image, text)")
-    ap.add_argument("--keep-fraction", type=float, default=0.88, help="share of the free HBM 'auto' may spend")
+    ap.add_argument("--keep-fraction", type=float, default=0.93, help="share of the free HBM 'auto' may spend")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="pairs per CPU-baseline step")
     ap.add_argument("--cpu-timeout", type=int, default=240)
@@ -185,17 +185,35 @@ def main():
         step()                                   # one extra untimed all-recompute step, only to measure its peak
         torch.cuda.synchronize()
         peak = torch.cuda.max_memory_allocated(dev)
-        budget = int(args.keep_fraction * (total_mem - peak)) - (6 << 30)
+        budget0 = int(args.keep_fraction * (total_mem - peak)) - (6 << 30)
         # Spend the budget where a byte saves the most recompute FLOPs: "medium" tier first (drops LN1, in-proj,
         # attention, out-proj: ~17.5 of a block's 25.5 D^2 units for 5 D bytes per token), image tower before
         # text (wider), then upgrades medium -> "light" (the remaining 8 units for 4 more D bytes).
         mv_b, mt_b = vt.medium_keep_bytes(B * L_img), tt.medium_keep_bytes(B * args.ctx)
         lv_b, lt_b = vt.light_keep_bytes(B * L_img), tt.light_keep_bytes(B * args.ctx)
-        med_v = max(0, min(cfg["vision_cfg"]["layers"], budget // mv_b)); budget -= med_v * mv_b
-        med_t = max(0, min(cfg["text_cfg"]["layers"], budget // mt_b)); budget -= med_t * mt_b
-        keep_v = max(0, min(med_v, budget // (lv_b - mv_b))); budget -= keep_v * (lv_b - mv_b)
-        keep_t = max(0, min(med_t, budget // (lt_b - mt_b)))
-        med_v, med_t = med_v - keep_v, med_t - keep_t
+
+        def plan(budget):
+            mv = max(0, min(cfg["vision_cfg"]["layers"], budget // mv_b)); budget -= mv * mv_b
+            mt = max(0, min(cfg["text_cfg"]["layers"], budget // mt_b)); budget -= mt * mt_b
+            kv = max(0, min(mv, budget // (lv_b - mv_b))); budget -= kv * (lv_b - mv_b)
+            kt = max(0, min(mt, budget // (lt_b - mt_b)))
+            return int(kv), int(kt), int(mv - kv), int(mt - kt)
+
+        keep_v, keep_t, med_v, med_t = plan(budget0)
+        if world == 1:
+            # trial step under the plan; an allocator-fragmentation OOM shrinks the budget instead of failing the run
+            # (single process only: with several ranks one rank backing off alone would desynchronise the collectives)
+            for attempt in range(4):
+                set_keep(keep_v, keep_t, med_v, med_t)
+                try:
+                    step()
+                    torch.cuda.synchronize()
+                    break
+                except torch.OutOfMemoryError:
+                    opt.zero_grad(set_to_none=True)
+                    torch.cuda.empty_cache()
+                    budget0 -= 12 << 30
+                    keep_v, keep_t, med_v, med_t = plan(budget0)
     else:
         vals = [int(v) for v in args.keep_blocks.split(",")]
         keep_v, keep_t = vals[0], vals[1]
@@ -244,6 +262,8 @@ def main():
                        "global_batch": B * world, "train_gflop_per_pair": round(gf, 2)},
             "model_flops_util": round(pairs_s / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4),
             "loss": round(last_loss, 4), "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
+            "peak_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2**30, 1),
+            "alloc_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)),
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA 32x32x16)", "achieved": round(achieved, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                          "traffic": traffic, "algorithmic_bytes_per_launch": round(nt.get("bytes", 0.0) / max(nt["launches"], 1)),
