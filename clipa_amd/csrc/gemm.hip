@@ -265,8 +265,14 @@ __device__ __forceinline__ void dma16(const u32x4 srd, unsigned lds_addr, unsign
 // the new phase are still in flight.
 constexpr int HS_BYTES = 32768;
 
-template <bool OUT_F32, bool SETPRIO, bool STAG = false>
+// M16 = true (bf16 output, non-STAG only): the main loop issues v_mfma_f32_16x16x32_bf16 (wave tile = 8 x 4
+// blocks of 16 x 16, fragment = 16 rows x 32 k: lane -> row l&15, chunk 4*kk + (l>>4); the image and its
+// (row>>1)&7 swizzle are unchanged and stay conflict-free for that read).  A quarter of the accumulator registers
+// are read and written per instruction: less register-file energy per FLOP, which is what counts under the power cap.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <bool OUT_F32, bool SETPRIO, bool STAG = false, bool M16 = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
+  static_assert(!M16 || (!OUT_F32 && !STAG), "16x16x32 variant: bf16 output, first-generation ring only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -367,12 +373,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
     if (has_next) tile_origin(base + it + gx, m1, n1);
 
     f32x16 acc[2][4];
+    f32x4v acc16[4][8];      // M16: [n block of 16][m block of 16]
+    if constexpr (M16) {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+      for (int bj = 0; bj < 4; ++bj)
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+        for (int ai = 0; ai < 8; ++ai) acc16[bj][ai] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+    }
 
     if constexpr (STAG) {
       const u32x4 rAc = srdA(m0), rBc = srdB(n0), rAn = srdA(m1), rBn = srdB(n1);
@@ -437,6 +451,39 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
       else if (has_next) stage((gk + 1) & 1, m1, n1, 0);
       const char* sA = smem + (gk & 1) * STAGE_BYTES;
       const char* sB = sA + IMG_BYTES;
+      if constexpr (M16) {
+        // 8 sub-steps per K tile: (kk, s) = 32-wide k-step kk, A blocks 2s and 2s+1 against the four B blocks of
+        // kk (8 MFMAs); A fragments double-buffered per sub-step, B fragments per k-step
+        const int l15 = lane & 15, g4 = lane >> 4, sw16 = (l15 >> 1) & 7;
+        const char* pa = sA + (wm * 128 + l15) * 128;
+        const char* pb = sB + (wn * 64 + l15) * 128;
+        bf16x8 ga[2][2], gb[2][4];
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj) gb[0][bj] = *(const bf16x8*)(pb + bj * 2048 + ((g4 ^ sw16) << 4));
+#pragma unroll
+        for (int a = 0; a < 2; ++a) ga[0][a] = *(const bf16x8*)(pa + a * 2048 + ((g4 ^ sw16) << 4));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int kk = u >> 2, sb = u & 3;
+          if (u < 7) {
+            const int k1 = (u + 1) >> 2, s1 = (u + 1) & 3;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) ga[(u + 1) & 1][a] = *(const bf16x8*)(pa + (2 * s1 + a) * 2048 + (((4 * k1 + g4) ^ sw16) << 4));
+          }
+          if (u == 1) {
+#pragma unroll
+            for (int bj = 0; bj < 4; ++bj) gb[1][bj] = *(const bf16x8*)(pb + bj * 2048 + (((4 + g4) ^ sw16) << 4));
+          }
+          if (SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+              acc16[bj][2 * sb + a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gb[kk][bj], ga[u & 1][a], acc16[bj][2 * sb + a], 0, 0, 0);
+          if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+        }
+        continue;
+      }
       bf16x8 fa[2][4], fb[2][2];
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) fa[0][mi] = *(const bf16x8*)(sA + rowoffA + mi * 4096 + ((hi ^ sw) << 4));
@@ -465,12 +512,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
     // ---- epilogue of tile (m0, n0); the ring keeps filling for the next tile meanwhile ----
     if (p.abl & 2) {   // ablation: keep the accumulators live, write nothing
       float t = 0.f;
+      if constexpr (M16) {
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+        for (int bj = 0; bj < 4; ++bj)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+          for (int ai = 0; ai < 8; ++ai) t += acc16[bj][ai][0] + acc16[bj][ai][1] + acc16[bj][ai][2] + acc16[bj][ai][3];
+      } else {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) t += acc[ni][mi][r];
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += acc[ni][mi][r];
+      }
       if (t == 1.2345e-30f) ((float*)p.C)[tid] = t;
     } else if (OUT_F32) {
       float* C = (float*)p.C;
@@ -497,12 +551,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
     } else {
       char* cb = smem + CBUF_OFF;
       const int epi = p.epi, act = p.act;
-      float4 bias4[2][4];
+      float4 bias4[2][4];     // M16 uses [0][bj]: the 4 consecutive features of n block bj this lane holds
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int n = n0 + wn * 64 + ni * 32 + 8 * q + 4 * hi;
+          if (M16 && ni == 1) continue;
+          const int n = M16 ? n0 + wn * 64 + q * 16 + 4 * (lane >> 4) : n0 + wn * 64 + ni * 32 + 8 * q + 4 * hi;
           bias4[ni][q] = (p.bias && n < p.N && !(p.abl & 4)) ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       // this thread's chunks of a pass: chunk c = j*512 + tid -> row c>>5 (0..63), 16-B column c&31.
@@ -524,7 +579,23 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
       for (int pass = 0; pass < 4; ++pass) {
         if ((pass & 1) == 0) fetch_aux(pass);
         LDS_BARRIER();   // readers of the previous pass are done with the window
-        if (wm == (pass >> 1)) {
+        if (M16 && wm == (pass >> 1)) {
+          // 16x16 blocks: lane holds features nl..nl+3 (nl = 16 bj + 4 (lane>>4)) of row 16 a2 + (lane & 15)
+#pragma unroll
+          for (int a2 = 0; a2 < 4; ++a2) {
+            const int ai = 4 * (pass & 1) + a2;
+            const int row = a2 * 16 + (lane & 15);
+#pragma unroll
+            for (int bj = 0; bj < 4; ++bj) {
+              const int nl = wn * 64 + bj * 16 + 4 * (lane >> 4);
+              const float4 b4 = bias4[0][bj];
+              u32x2 w;
+              w[0] = pack2bf(acc16[bj][ai][0] * p.alpha + b4.x, acc16[bj][ai][1] * p.alpha + b4.y);
+              w[1] = pack2bf(acc16[bj][ai][2] * p.alpha + b4.z, acc16[bj][ai][3] * p.alpha + b4.w);
+              *(u32x2*)(cb + row * 512 + ((((nl >> 3) ^ row) & 31) << 4) + (nl & 7) * 2) = w;
+            }
+          }
+        } else if (wm == (pass >> 1)) {
 #pragma unroll
           for (int mi2 = 0; mi2 < 2; ++mi2) {
             const int mi = 2 * (pass & 1) + mi2;
@@ -1277,7 +1348,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TNArgs p) {
 // per instruction, i.e. ~20 % less register-file traffic per FLOP - does that buy clock under the power cap?
 // (tools/gemm_ab.py variant 16.)  Fragment = 16 rows x 32 k: lane -> row l&15, 16-byte chunk l>>4; chunk
 // permutation {0,2,3,1}[(row>>2)&3] keeps the 64-byte-row image conflict-free for that read.
-typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define WG_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 __global__ __launch_bounds__(NTHREADS) void gemm_nt16_probe_kernel(NTArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1393,6 +1463,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt16_probe_kernel(NTArgs p) {
 // slabs of 32 rows (P [32][256] + Q [32][256] = one 32 KiB half-slot, ring of four, three slabs in flight,
 // counted vmcnt(8)); every wave alternates LOAD (24 ds_read_b64_tr_b16 = both k-steps of a slab, its 4 DMA
 // pieces of slab s+3) and COMPUTE (16 MFMAs from registers) with an s_barrier after each, and waves 4-7 run
+// (a 16x16x32 port of this loop measured 3-6 % slower than 32x32x16 here, unlike in gemm_nt, and was dropped)
 // one barrier behind waves 0-3, so each SIMD always has one wave in its MFMA block beside the other wave's
 // LDS phase.  There are no stores in the loop, so every wave can feed the DMA ring.
 #define TN_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -1572,7 +1643,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, void* __res
 
 bool g_attr_done = false;
 int g_num_cu = 256;
-int g_nt_variant = 5;
+int g_nt_variant = 11;
 int g_abl = 0;
 int ensure_attrs() {
   if (g_attr_done) return 0;
@@ -1585,10 +1656,10 @@ int ensure_attrs() {
   if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_tn2): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
   e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
   if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_tn): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
-  const void* v2[5] = {(const void*)gemm_nt2_kernel<false, false>, (const void*)gemm_nt2_kernel<false, true>,
+  const void* v2[6] = {(const void*)gemm_nt2_kernel<false, false>, (const void*)gemm_nt2_kernel<false, true>,
                        (const void*)gemm_nt2_kernel<true, false>, (const void*)gemm_nt2_kernel<true, true>,
-                       (const void*)gemm_nt2_kernel<false, true, true>};
-  for (int i = 0; i < 5; ++i) {
+                       (const void*)gemm_nt2_kernel<false, true, true>, (const void*)gemm_nt2_kernel<false, true, false, true>};
+  for (int i = 0; i < 6; ++i) {
     e = hipFuncSetAttribute(v2[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES);
     if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_nt2): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
   }
@@ -1660,7 +1731,8 @@ extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, co
     hipLaunchKernelGGL((gemm_nt2_kernel<false, true, true>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
     return clipa_check_launch("gemm_nt4");
   }
-  if (g_nt_variant >= 5 && !out_f32 && K >= 3 * BK && (epi == CLIPA_EPI_NONE || g_nt_variant == 6)) {
+  // 10: 16x16x32 MFMAs (v2 ring) for the fused epilogues, roles for plain; 11: 16x16x32 v2 for everything.
+  if (g_nt_variant >= 5 && g_nt_variant != 11 && !out_f32 && K >= 3 * BK && (epi == CLIPA_EPI_NONE || g_nt_variant == 6)) {
     const unsigned grid = (unsigned)(tiles < g_num_cu ? tiles : g_num_cu);
     if (epi == CLIPA_EPI_ACT) hipLaunchKernelGGL((gemm_nt3_kernel<CLIPA_EPI_ACT, true>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
     else if (epi == CLIPA_EPI_ADD) hipLaunchKernelGGL((gemm_nt3_kernel<CLIPA_EPI_ADD, true>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
@@ -1671,7 +1743,8 @@ extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, co
   if (g_nt_variant >= 2) {
     const unsigned grid = (unsigned)(tiles < g_num_cu ? tiles : g_num_cu);
     const bool prio = g_nt_variant == 3 || g_nt_variant == 5;
-    if (out_f32 && prio) hipLaunchKernelGGL((gemm_nt2_kernel<true, true>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
+    if (!out_f32 && (g_nt_variant == 10 || g_nt_variant == 11)) hipLaunchKernelGGL((gemm_nt2_kernel<false, true, false, true>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
+    else if (out_f32 && prio) hipLaunchKernelGGL((gemm_nt2_kernel<true, true>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
     else if (out_f32) hipLaunchKernelGGL((gemm_nt2_kernel<true, false>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
     else if (prio) hipLaunchKernelGGL((gemm_nt2_kernel<false, true>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
     else hipLaunchKernelGGL((gemm_nt2_kernel<false, false>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);

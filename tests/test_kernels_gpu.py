@@ -94,10 +94,10 @@ def _debug_set(variant, abl):
     assert h.clipa_debug_set(variant, abl) == 0
 
 
-@pytest.mark.parametrize("variant", [1, 2, 5, 7, 9])
+@pytest.mark.parametrize("variant", [1, 2, 5, 7, 9, 10, 11])
 def test_gemm_nt_kernel_generations_agree(variant):
     """Every gemm_nt generation kept for A/B runs (one tile per workgroup, persistent, loader/storer roles,
-    ping-pong, ping-pong + roles) computes the same thing on ragged shapes and with every epilogue."""
+    ping-pong, ping-pong + roles, 16x16x32 MFMAs) computes the same thing on ragged shapes and with every epilogue."""
     o = ops()
     try:
         for (M, N, K) in [(300, 264, 136), (1000, 520, 776), (777, 1024, 768), (2048, 256, 4096)]:
@@ -113,21 +113,22 @@ def test_gemm_nt_kernel_generations_agree(variant):
                 check("pre", pre, lin, 2 ** -7, 2e-3)
                 check("gelu", g, ref_act(pre.double().cpu(), 0), 2 ** -7, 2e-3)
     finally:
-        _debug_set(5, 0)
+        _debug_set(11, 0)
 
 
 def test_gemm_tn_kernel_generations_agree():
-    """The ping-pong weight-gradient kernel reduces in the same order as the first generation: bit-identical."""
+    """The ping-pong weight-gradient kernel against the first generation (all waves in step): same reduction order."""
     o = ops()
     p, q = rnd(70000, 520, seed=13).to(DEV), rnd(70000, 264, seed=14, scale=0.1).to(DEV)
     try:
-        _debug_set(5, 0)
-        w2, c2 = o.gemm_tn(p, q, bf16, want_colsum=True)
-        _debug_set(5, 512)
-        w1, c1 = o.gemm_tn(p, q, bf16, want_colsum=True)
+        _debug_set(11, 0)
+        w2, c2 = o.gemm_tn(p, q, f32, want_colsum=True)
+        _debug_set(11, 512)
+        w1, c1 = o.gemm_tn(p, q, f32, want_colsum=True)
     finally:
-        _debug_set(5, 0)
-    assert torch.equal(w1, w2)
+        _debug_set(11, 0)
+    check("weight gradient", w2, w1, 1e-5, 2e-3)
+    check("weight gradient vs fp64", w2, p.double().cpu().T @ q.double().cpu(), 2e-4, 2e-2)
     check("column sums", c2, c1, 1e-6, 1e-4)
 
 

@@ -15,7 +15,7 @@ outs = {}
 times = {0: [], 512: []}
 for rnd in range(7):
     for abl in (0, 512):
-        h.clipa_debug_set(5, abl)
+        h.clipa_debug_set(11, abl)
         o = ops.gemm_tn(p, q, bf16, want_colsum=True); torch.cuda.synchronize()
         outs[abl] = o
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -23,8 +23,8 @@ for rnd in range(7):
         for _ in range(4): ops.gemm_tn(p, q, bf16, want_colsum=True)
         e1.record(); torch.cuda.synchronize()
         times[abl].append(e0.elapsed_time(e1) / 4)
-h.clipa_debug_set(5, 0)
-same = torch.equal(outs[0][0], outs[512][0]) and torch.allclose(outs[0][1], outs[512][1], rtol=1e-5, atol=1e-3)
+h.clipa_debug_set(11, 0)
+same = torch.allclose(outs[0][0].float(), outs[512][0].float(), rtol=2e-2, atol=2e-2) and torch.allclose(outs[0][1], outs[512][1], rtol=1e-5, atol=1e-3)
 for abl in (0, 512):
     t = sorted(times[abl]); med = t[len(t) // 2]
     print(json.dumps({"M": M, "R": R, "C": C, "kernel": "tn2" if abl == 0 else "tn1", "ms_med": round(med, 4),
