@@ -1342,6 +1342,162 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TNArgs p) {
   }
 }
 
+// gemm_tn v3 = the first-generation schedule (one barrier per 64 rows, all waves in step, register prefetch) on
+// v_mfma_f32_16x16x32_bf16 with the sub-step interleave of gemm_nt2's 16x16x32 loop (A/B: ablation bit 1024).
+__device__ __forceinline__ int tn_swz16(int row) { return ((row & 3) << 2) ^ (((row >> 3) & 1) << 1); }
+__global__ __launch_bounds__(NTHREADS) void gemm_tn3_kernel(TNArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wr = wave >> 2, wc = wave & 3;   // wave tile: 128 (r) x 64 (c)
+
+  const int tilesC = (p.C + 255) / 256;
+  const int tilesR = (p.R + 255) / 256;
+  const unsigned t = xcd_remap(blockIdx.x, (unsigned)(tilesR * tilesC));
+  const int tr = t / tilesC, tc = t - tr * tilesC;
+  const int r0 = tr * 256, c0 = tc * 256;
+  const int slice = blockIdx.y;
+  const long mbeg = (long)slice * p.slice_rows;
+  const long mend = min((long)p.M, mbeg + p.slice_rows);
+  float* O = p.O + (size_t)slice * p.R * p.ldo;
+
+  // SRD base = first row of the slice, first column of the tile; rows >= M read zeros.
+  const long rows_left = p.M - mbeg;
+  auto nrec = [&](long ld, int col0) -> unsigned {
+    long b = rows_left * ld * 2 - (long)col0 * 2;
+    if (b < 0) b = 0;
+    return (unsigned)(b > 0xffffffffL ? 0xffffffffL : b);
+  };
+  const __amdgpu_buffer_rsrc_t rsP = make_rsrc(p.P + ((size_t)mbeg * p.ldp + r0) * 2, nrec(p.ldp, r0));
+  const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.Q + ((size_t)mbeg * p.ldq + c0) * 2, nrec(p.ldq, c0));
+
+  // DMA piece pc = j*8+wave covers image rows 2pc, 2pc+1 (512 B each).
+  unsigned voffP[4], voffQ[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (j * 8 + wave) * 2 + (lane >> 5);
+    const int chunk = (lane & 31) ^ tn_swz16(row);
+    voffP[j] = (unsigned)(row * p.ldp * 2 + chunk * 16);
+    voffQ[j] = (unsigned)(row * p.ldq * 2 + chunk * 16);
+  }
+
+  f32x4v acc[8][4];      // [r block of 16][c block of 16]
+#pragma unroll
+  for (int ri = 0; ri < 8; ++ri)
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) acc[ri][ci] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  auto stage = [&](int buf, long mrow) {   // mrow relative to mbeg
+    char* sP = smem + buf * STAGE_BYTES;
+    char* sQ = sP + IMG_BYTES;
+    const unsigned soffP = (unsigned)(mrow * p.ldp * 2), soffQ = (unsigned)(mrow * p.ldq * 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int pc = j * 8 + wave;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, LDS_PTR(sP + pc * 1024), 16, voffP[j], soffP, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, LDS_PTR(sQ + pc * 1024), 16, voffQ[j], soffQ, 0, 0);
+    }
+  };
+
+  // transpose-read addressing: lane (hi, q, i): row = ms*16 + 8*hi + 4*half + (i>>2),
+  // col = colbase + 16*q + 4*(i&3)  ->  returns (rows +0..3, col colbase+16q+i)
+  // 16x16x32 fragment: lane (g = l>>4, i = l&15) -> rows kk*32 + 8g + 4*half + (i>>2), columns colbase + 4*(i&3) .. +3
+  const int g4 = lane >> 4, i16 = lane & 15;
+  const int rsub = 8 * g4 + (i16 >> 2);          // + kk*32 + 4*half
+  const int csub = 4 * (i16 & 3);                // + colbase (multiple of 16)
+
+  const bool do_colsum = p.colsum != nullptr && tc == 0;   // one C-tile column of workgroups owns the sums
+  const int cs_ch = tid & 31, cs_rg = tid >> 5;             // 32 column chunks x 16 row groups
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int nmt = (int)((mend - mbeg + 63) / 64);
+  if (nmt > 0) stage(0, 0);
+  for (int mt = 0; mt < nmt; ++mt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (mt + 1 < nmt) stage((mt + 1) & 1, (long)(mt + 1) * 64);
+    const char* sP = smem + (mt & 1) * STAGE_BYTES;
+    const char* sQ = sP + IMG_BYTES;
+    if (do_colsum) {
+      // column sums of the P tile (64 m-rows x 256 columns): thread = (16-B column chunk, group of 4 rows)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int row = cs_rg * 4 + rr;
+        float f[8];
+        unpack8(*(const u32x4*)(sP + row * 512 + ((cs_ch ^ tn_swz16(row)) << 4)), f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) csum[i] += f[i];
+      }
+    }
+    // 8 sub-steps per 64-row tile: (kk, s) = 32-row k-step kk, P blocks 2s and 2s+1 against the four Q blocks of kk
+    // (8 MFMAs); P fragments double-buffered per sub-step, Q fragments per k-step
+    auto frag = [&](const char* img, int kk, int colbase) {
+      bf16x8 f;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int row = kk * 32 + 4 * half + rsub;
+        const int col = colbase + csub;
+        const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) bf16x4*)(img + row * 512 + (((col >> 3) ^ tn_swz16(row)) << 4) + (col & 7) * 2));
+        f[4 * half + 0] = v[0]; f[4 * half + 1] = v[1]; f[4 * half + 2] = v[2]; f[4 * half + 3] = v[3];
+      }
+      return f;
+    };
+    bf16x8 gp[2][2], gq[2][4];
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) gq[0][ci] = frag(sQ, 0, wc * 64 + ci * 16);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) gp[0][a] = frag(sP, 0, wr * 128 + a * 16);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int kk = u >> 2, sb = u & 3;
+      if (u < 7) {
+        const int k1 = (u + 1) >> 2, s1 = (u + 1) & 3;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) gp[(u + 1) & 1][a] = frag(sP, k1, wr * 128 + (2 * s1 + a) * 16);
+      }
+      if (u == 1) {
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) gq[1][ci] = frag(sQ, 1, wc * 64 + ci * 16);
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+          acc[2 * sb + a][ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gp[u & 1][a], gq[kk][ci], acc[2 * sb + a][ci], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+
+  // D[r][c]: lane holds c = cblock + (l & 15), r = rblock + 4*(l >> 4) + e
+#pragma unroll
+  for (int ri = 0; ri < 8; ++ri)
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+      const int c = c0 + wc * 64 + ci * 16 + i16;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = r0 + wr * 128 + ri * 16 + 4 * g4 + e;
+        if (r < p.R && c < p.C) O[(size_t)r * p.ldo + c] = acc[ri][ci][e];
+      }
+    }
+  if (do_colsum) {
+    __syncthreads();                       // every wave is done with the ring: reuse it as [16][256] floats
+    float* red = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[cs_rg * 256 + cs_ch * 8 + i] = csum[i];
+    __syncthreads();
+    if (tid < 256) {
+      float a = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) a += red[g * 256 + tid];
+      if (r0 + tid < p.R) p.colsum[(size_t)slice * p.R + r0 + tid] = a;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // PROBE (main loop only, writes nothing useful): the v2 ping-pong loop on v_mfma_f32_16x16x32_bf16 instead of
 // 32x32x16.  Same LDS bytes and MFMA FLOP rate; a quarter of the accumulator registers are read and written
@@ -1652,6 +1808,8 @@ int ensure_attrs() {
   if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_nt<bf16>): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
   e = hipFuncSetAttribute((const void*)gemm_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_nt<f32>): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
+  e = hipFuncSetAttribute((const void*)gemm_tn3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+  if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_tn3): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
   e = hipFuncSetAttribute((const void*)gemm_tn2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
   if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_tn2): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
   e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
@@ -1785,7 +1943,12 @@ extern "C" int clipa_gemm_tn(const void* P, const void* Q, void* out, float* col
   a.colsum = colsum_out ? (float*)workspace + S * R * C : nullptr;
   const long tiles = ((R + 255) / 256) * ((C + 255) / 256);
   // ablation bit 9 (512) selects the first-generation kernel (one barrier per 64 rows, all waves in step)
-  if (g_abl & 512) hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)tiles, (unsigned)S), dim3(NTHREADS), 2 * STAGE_BYTES, (hipStream_t)stream, a);
+  // Default: the 16x16x32 first-generation schedule (v3) for wide-P products (R >= 4096: the c_fc weight gradient)
+  // and small square ones, the ping-pong kernel (v2) elsewhere - per-shape winners of tools/tn_ab.py, all within
+  // +-4 % except the text tower (v2 +18 %).  Ablation bits force one kernel: 512 v1, 1024 v3, 2048 v2.
+  const bool use_v3 = (g_abl & 1024) || (!(g_abl & (512 | 2048)) && (R >= 4096 || (R <= 1024 && C <= 1024)));
+  if (use_v3) hipLaunchKernelGGL(gemm_tn3_kernel, dim3((unsigned)tiles, (unsigned)S), dim3(NTHREADS), 2 * STAGE_BYTES, (hipStream_t)stream, a);
+  else if (g_abl & 512) hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)tiles, (unsigned)S), dim3(NTHREADS), 2 * STAGE_BYTES, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(gemm_tn2_kernel, dim3((unsigned)tiles, (unsigned)S), dim3(NTHREADS), 2 * STAGE_BYTES, (hipStream_t)stream, a);
   if (int rc = clipa_check_launch("gemm_tn")) return rc;
   const long n = R * C;

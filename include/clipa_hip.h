@@ -45,7 +45,7 @@ int clipa_version(void);
  * for plain/bias epilogues, 3 for fused ones; 6 roles for every epilogue; 7 ping-pong main loop; 8 = 7 for fused
  * epilogues, roles for plain; 9 ping-pong + roles (gemm_nt5) for plain, 7 for fused; 16 main-loop probe on 16x16x32 MFMAs (writes nothing).  Ablation bit flags: 1 no
  * global stores, 2 no epilogue, 4 no bias, 8 row-major tile order, 16 spread DMA issue, 32 alias stores into
- * 256 rows, 512 first-generation gemm_tn.  Production callers never touch it. */
+ * 256 rows, 512 / 1024 / 2048 force gemm_tn v1 / v3 / v2.  Production callers never touch it. */
 int clipa_debug_set(int gemm_nt_variant, int ablation_flags);
 
 /* C[M,N] = epi(alpha * A[M,K] . B[N,K]^T + bias[N]); A,B bf16; C bf16 (or f32 when out_f32, epi NONE).
