@@ -45,7 +45,79 @@ __global__ void adamw_kernel(void* __restrict__ param, const void* __restrict__ 
     else ((unsigned short*)param)[i] = f2bf(p);
   }
 }
+// Multi-tensor form: up to MT_MAX tensors per launch, their pointers and sizes travel in the kernel argument
+// (no device-side table to fill); block b works on a 4096-element chunk of the tensor whose block range holds b.
+constexpr int MT_MAX = 48;
+constexpr int MT_CHUNK = 4096;
+struct MTArgs {
+  void* p[MT_MAX];
+  const void* g[MT_MAX];
+  float* m[MT_MAX];
+  float* v[MT_MAX];
+  long n[MT_MAX];
+  int blk0[MT_MAX + 1];
+  int count;
+  float lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale;
+};
+template <bool PF32, bool GF32>
+__global__ void adamw_multi_kernel(MTArgs a) {
+  int t = 0;
+  while (t + 1 < a.count && (int)blockIdx.x >= a.blk0[t + 1]) ++t;
+  const long base = (long)((int)blockIdx.x - a.blk0[t]) * MT_CHUNK;
+  const long n = a.n[t];
+  void* param = a.p[t];
+  const void* grad = a.g[t];
+  float* m = a.m[t];
+  float* v = a.v[t];
+  for (long i = base + threadIdx.x; i < n && i < base + MT_CHUNK; i += blockDim.x) {
+    float p = PF32 ? ((float*)param)[i] : bf2f(((unsigned short*)param)[i]);
+    const float g = (GF32 ? ((const float*)grad)[i] : bf2f(((const unsigned short*)grad)[i])) * a.gscale;
+    p *= 1.0f - a.lr * a.wd;
+    const float mi = a.b1 * m[i] + (1.0f - a.b1) * g;
+    const float vi = a.b2 * v[i] + (1.0f - a.b2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
+    p -= (a.lr / a.bc1) * (mi / denom);
+    if (PF32) ((float*)param)[i] = p;
+    else ((unsigned short*)param)[i] = f2bf(p);
+  }
+}
 }  // namespace
+
+extern "C" int clipa_adamw_multi(void* const* params, const void* const* grads, float* const* exp_avg,
+                                 float* const* exp_avg_sq, const int64_t* numel, int count, int param_f32,
+                                 int grad_f32, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                 int64_t step, float grad_scale, void* stream) {
+  if (count <= 0) return CLIPA_OK;
+  if (step < 1) { clipa_set_error("adamw_multi: step must be >= 1"); return CLIPA_ERR_ARG; }
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !numel) { clipa_set_error("adamw_multi: null table"); return CLIPA_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  for (int first = 0; first < count; first += MT_MAX) {
+    MTArgs a;
+    a.count = 0;
+    a.blk0[0] = 0;
+    for (int i = first; i < count && a.count < MT_MAX; ++i) {
+      if (numel[i] <= 0) continue;
+      const int c = a.count++;
+      a.p[c] = params[i]; a.g[c] = grads[i]; a.m[c] = exp_avg[i]; a.v[c] = exp_avg_sq[i]; a.n[c] = (long)numel[i];
+      a.blk0[c + 1] = a.blk0[c] + (int)((numel[i] + MT_CHUNK - 1) / MT_CHUNK);
+    }
+    if (a.count == 0) continue;
+    a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = weight_decay; a.gscale = grad_scale;
+    a.bc1 = 1.0f - powf(beta1, (float)step);
+    a.bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    const unsigned grid = (unsigned)a.blk0[a.count];
+#define LAUNCH(P, G) hipLaunchKernelGGL((adamw_multi_kernel<P, G>), dim3(grid), dim3(256), 0, st, a)
+    if (param_f32 && grad_f32) LAUNCH(true, true);
+    else if (param_f32) LAUNCH(true, false);
+    else if (grad_f32) LAUNCH(false, true);
+    else LAUNCH(false, false);
+#undef LAUNCH
+    if (int rc = clipa_check_launch("adamw_multi")) return rc;
+  }
+  return CLIPA_OK;
+}
 
 extern "C" int clipa_adamw(void* param, const void* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                            int param_f32, int grad_f32, float lr, float beta1, float beta2, float eps,

@@ -46,6 +46,7 @@ SIGNATURES = {
     "clipa_ce_rows": (_I32, [_P, _I64, _I64, _I64, _I64, _F, _P, _I64, _P, _P, _P]),
     "clipa_sum_scale": (_I32, [_P, _P, _I64, _F, _I32, _P]),
     "clipa_adamw": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _F, _F, _F, _F, _F, _I64, _F, _P]),
+    "clipa_adamw_multi": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _F, _F, _F, _F, _F, _I64, _F, _P]),
 }
 
 _lib = None

@@ -379,3 +379,20 @@ def adamw_(param, grad, exp_avg, exp_avg_sq, *, lr, beta1, beta2, eps, weight_de
     lib.call("clipa_adamw", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), int(param.dtype == f32),
              int(grad.dtype == f32), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
              float(grad_scale), _stream())
+
+
+def adamw_multi_(params, grads, exp_avgs, exp_avg_sqs, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    """One AdamW update over a list of tensors that share dtypes, hyper-parameters and step count."""
+    n = len(params)
+    if n == 0:
+        return
+    pf32, gf32 = params[0].dtype == f32, grads[0].dtype == f32
+    for t, g in zip(params, grads):
+        if (t.dtype == f32) != pf32 or (g.dtype == f32) != gf32 or not t.is_cuda:
+            raise RuntimeError("adamw_multi_: mixed dtypes in one call / tensors must live on the GPU")
+    arr = ctypes.c_void_p * n
+    cnt = (ctypes.c_int64 * n)(*[t.numel() for t in params])
+    lib.call("clipa_adamw_multi", arr(*[t.data_ptr() for t in params]), arr(*[t.data_ptr() for t in grads]),
+             arr(*[t.data_ptr() for t in exp_avgs]), arr(*[t.data_ptr() for t in exp_avg_sqs]), cnt, n, int(pf32),
+             int(gf32), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+             float(grad_scale), _stream())

@@ -132,6 +132,12 @@ int clipa_sum_scale(const float* in, float* out, int64_t n, float scale, int acc
 int clipa_adamw(void* param, const void* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int param_f32,
                 int grad_f32, float lr, float beta1, float beta2, float eps, float weight_decay,
                 int64_t step, float grad_scale, void* stream);
+/* The same update over `count` tensors that share dtypes, hyper-parameters and step (one parameter group of
+ * main.py:311-326): HOST arrays of device pointers / element counts; a few launches instead of one per tensor. */
+int clipa_adamw_multi(void* const* params, const void* const* grads, float* const* exp_avg,
+                      float* const* exp_avg_sq, const int64_t* numel, int count, int param_f32, int grad_f32,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                      float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -193,3 +193,8 @@ def adamw_(param, grad, exp_avg, exp_avg_sq, *, lr, beta1, beta2, eps, weight_de
     exp_avg_sq.mul_(beta2).addcmul_(g, g, value=1 - beta2)
     denom = exp_avg_sq.sqrt() / math.sqrt(1 - beta2 ** step) + eps
     param.copy_((p - lr / (1 - beta1 ** step) * exp_avg / denom).to(param.dtype))
+
+
+def adamw_multi_(params, grads, exp_avgs, exp_avg_sqs, **kw):
+    for p, g, m, v in zip(params, grads, exp_avgs, exp_avg_sqs):
+        adamw_(p, g, m, v, **kw)

@@ -316,6 +316,27 @@ def test_cross_entropy_rows(R, N, label0):
     check("sum", ops().sum_scale(loss_rows, gs), per.sum() * gs, 1e-5, 1e-6)
 
 
+@pytest.mark.parametrize("pdt,gdt", [(f32, f32), (bf16, bf16)])
+def test_adamw_multi_tensor_equals_per_tensor(pdt, gdt):
+    """One multi-tensor call (more tensors than fit one launch, ragged sizes incl. 1 and > one chunk) gives the
+    result of the per-tensor kernel (same formula; the two kernels may contract one FMA differently)."""
+    sizes = [1, 7, 4096, 4097, 10007, 300 * 1024 + 5] + [33 + 17 * i for i in range(60)]
+    ps = [rnd(n, seed=100 + i, dtype=f32).to(pdt).to(DEV) for i, n in enumerate(sizes)]
+    gs = [rnd(n, seed=300 + i, dtype=f32, scale=0.1).to(gdt).to(DEV) for i, n in enumerate(sizes)]
+    one = [t.clone() for t in ps]
+    m1, v1 = [torch.zeros(n, device=DEV) for n in sizes], [torch.zeros(n, device=DEV) for n in sizes]
+    m2, v2 = [torch.zeros(n, device=DEV) for n in sizes], [torch.zeros(n, device=DEV) for n in sizes]
+    kw = dict(lr=1e-3, beta1=0.9, beta2=0.95, eps=1e-6, weight_decay=0.2)
+    for step in (1, 2):
+        for p, g, m, v in zip(one, gs, m1, v1):
+            ops().adamw_(p, g, m, v, step=step, **kw)
+        ops().adamw_multi_(ps, gs, m2, v2, step=step, **kw)
+    ptol = 2 ** -7 if pdt == bf16 else 2e-6
+    for a, b, ma, mb, va, vb in zip(one, ps, m1, m2, v1, v2):
+        assert torch.allclose(a.float(), b.float(), rtol=ptol, atol=1e-7)
+        assert torch.allclose(ma, mb, rtol=2e-6, atol=1e-12) and torch.allclose(va, vb, rtol=2e-6, atol=1e-12)
+
+
 @pytest.mark.parametrize("pdt,gdt", [(f32, f32), (bf16, bf16), (f32, bf16)])
 def test_adamw_matches_torch(pdt, gdt):
     n = 10007
