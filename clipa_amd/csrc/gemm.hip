@@ -1499,122 +1499,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn3_kernel(TNArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// PROBE (main loop only, writes nothing useful): the v2 ping-pong loop on v_mfma_f32_16x16x32_bf16 instead of
-// 32x32x16.  Same LDS bytes and MFMA FLOP rate; a quarter of the accumulator registers are read and written
-// per instruction, i.e. ~20 % less register-file traffic per FLOP - does that buy clock under the power cap?
-// (tools/gemm_ab.py variant 16.)  Fragment = 16 rows x 32 k: lane -> row l&15, 16-byte chunk l>>4; chunk
-// permutation {0,2,3,1}[(row>>2)&3] keeps the 64-byte-row image conflict-free for that read.
-#define WG_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-__global__ __launch_bounds__(NTHREADS) void gemm_nt16_probe_kernel(NTArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-  const int tilesN = (p.N + BN - 1) / BN, tilesM = (p.M + BM - 1) / BM;
-  const unsigned ntiles = (unsigned)(tilesM * tilesN);
-  const unsigned G = gridDim.x, xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
-  const unsigned gx = (G - xcd + 7u) >> 3;
-  const unsigned q8 = ntiles >> 3, r8 = ntiles & 7u;
-  const unsigned base = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-  const unsigned len = q8 + (xcd < r8 ? 1u : 0u);
-  auto tile_origin = [&](unsigned t, int& m0, int& n0) {
-    const int GM = 4, per = GM * tilesN;
-    const int g = (int)t / per, r = (int)t - g * per;
-    const int gm = min(GM, tilesM - g * GM);
-    const int tn = r / gm, mm = r - tn * gm;
-    m0 = (g * GM + mm) * BM;
-    n0 = tn * BN;
-  };
-  auto p4 = [](int x) { return (0x78 >> (2 * x)) & 3; };
-  const int chunk4 = (lane & 3) ^ p4((lane >> 4) & 3);
-  const int row4 = wave * 16 + (lane >> 2);
-  const unsigned voffA0 = (unsigned)(row4 * p.lda * 2 + chunk4 * 16), voffA1 = voffA0 + (unsigned)(128 * p.lda * 2);
-  const unsigned voffB0 = (unsigned)(row4 * p.ldb * 2 + chunk4 * 16), voffB1 = voffB0 + (unsigned)(128 * p.ldb * 2);
-  const int np = (p.K + 31) / 32;
-  auto stage4 = [&](unsigned slot, const u32x4 rsA, const u32x4 rsB, int k0) {
-    const unsigned oob = (k0 + chunk4 * 8 >= p.K) ? 0x80000000u : 0u;
-    const unsigned d = lds0 + slot * HS_BYTES + wave * 1024;
-    dma16(rsA, d, voffA0 | oob, (unsigned)(k0 * 2));
-    dma16(rsA, d + 8192, voffA1 | oob, (unsigned)(k0 * 2));
-    dma16(rsB, d + 16384, voffB0 | oob, (unsigned)(k0 * 2));
-    dma16(rsB, d + 16384 + 8192, voffB1 | oob, (unsigned)(k0 * 2));
-  };
-  auto srdA = [&](int m) { return make_srd(p.A + (size_t)m * p.lda * 2, (unsigned)(min(BM, p.M - m) * p.lda * 2)); };
-  auto srdB = [&](int n) { return make_srd(p.B + (size_t)n * p.ldb * 2, (unsigned)(min(BN, p.N - n) * p.ldb * 2)); };
-  if (idx >= len) return;
-  unsigned it = idx;
-  int m0, n0;
-  tile_origin(base + it, m0, n0);
-  {
-    const u32x4 a = srdA(m0), b = srdB(n0);
-    stage4(0, a, b, 0);
-    stage4(1, a, b, 32);
-    stage4(2, a, b, 64);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    WG_BARRIER_LDS();
-  }
-  const int l15 = lane & 15;
-  const int cph = ((lane >> 4) ^ p4((l15 >> 2) & 3)) << 4;
-  const int offA = (wm * 128 + l15) * 64 + cph, offB = (wn * 64 + l15) * 64 + cph;
-  unsigned gk = 0;
-  float sink = 0.f;
-  for (;;) {
-    const bool has_next = it + gx < len;
-    int m1 = 0, n1 = 0;
-    if (has_next) tile_origin(base + it + gx, m1, n1);
-    const u32x4 rAc = srdA(m0), rBc = srdB(n0), rAn = srdA(m1), rBn = srdB(n1);
-    f32x4v acc[4][8];
-#pragma unroll
-    for (int bj = 0; bj < 4; ++bj)
-#pragma unroll
-      for (int ai = 0; ai < 8; ++ai) acc[bj][ai] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    bf16x8 fa[8], fb[4];
-    if (wm == 1) WG_BARRIER_LDS();
-    for (int sl = 0; sl < np; ++sl, ++gk) {
-      const char* sA = smem + (gk & 3) * HS_BYTES + offA;
-      const char* sB = smem + (gk & 3) * HS_BYTES + 16384 + offB;
-#pragma unroll
-      for (int ai = 0; ai < 8; ++ai) fa[ai] = *(const bf16x8*)(sA + ai * 1024);
-#pragma unroll
-      for (int bj = 0; bj < 4; ++bj) fb[bj] = *(const bf16x8*)(sB + bj * 1024);
-      {
-        const int q = sl + 3;
-        if (q < np) stage4((gk + 3) & 3, rAc, rBc, q * 32);
-        else if (has_next) stage4((gk + 3) & 3, rAn, rBn, (q - np) * 32);
-      }
-      if (sl >= 2) {
-        if (!has_next && sl + 3 >= np) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      }
-      WG_BARRIER_LDS();
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int bj = 0; bj < 4; ++bj)
-#pragma unroll
-        for (int ai = 0; ai < 8; ++ai)
-          acc[bj][ai] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[bj], fa[ai], acc[bj][ai], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      WG_BARRIER_LDS();
-    }
-    if (wm == 0) WG_BARRIER_LDS();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    WG_BARRIER_LDS();
-#pragma unroll
-    for (int bj = 0; bj < 4; ++bj)
-#pragma unroll
-      for (int ai = 0; ai < 8; ++ai) sink += acc[bj][ai][0] + acc[bj][ai][1] + acc[bj][ai][2] + acc[bj][ai][3];
-    if (!has_next) break;
-    it += gx;
-    m0 = m1;
-    n0 = n1;
-  }
-  if (sink == 1.2345e-30f) ((float*)p.C)[tid] = sink;
-}
-#undef WG_BARRIER_LDS
-
-// ------------------------------------------------------------------------------------------------
 // gemm_tn v2: the same product with the PING-PONG schedule of gemm_nt v5.  The reduction axis is walked in
 // slabs of 32 rows (P [32][256] + Q [32][256] = one 32 KiB half-slot, ring of four, three slabs in flight,
 // counted vmcnt(8)); every wave alternates LOAD (24 ds_read_b64_tr_b16 = both k-steps of a slab, its 4 DMA
@@ -1827,8 +1711,6 @@ int ensure_attrs() {
     e = hipFuncSetAttribute(v3[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES);
     if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_nt3): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
   }
-  e = hipFuncSetAttribute((const void*)gemm_nt16_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES);
-  if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_nt16_probe): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
   e = hipFuncSetAttribute((const void*)gemm_nt5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES);
   if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_nt5): %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
   int dev = 0;
@@ -1872,12 +1754,6 @@ extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, co
   // 6: role split for every epilogue (experiments).
   // 7: staggered two-group main loop ("nt4") for every bf16-output GEMM; 8: nt4 for the fused epilogues, role
   // split for plain ones.
-  // 16: main-loop probe on 16x16x32 MFMAs (no output; timing experiments only)
-  if (g_nt_variant == 16 && !out_f32 && K >= 96) {
-    const unsigned grid = (unsigned)(tiles < g_num_cu ? tiles : g_num_cu);
-    hipLaunchKernelGGL(gemm_nt16_probe_kernel, dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
-    return clipa_check_launch("gemm_nt16_probe");
-  }
   // 9: v5 (ping-pong + wave roles) for plain / bias epilogues, ping-pong v2 for the fused ones.
   if (g_nt_variant == 9 && epi == CLIPA_EPI_NONE && !out_f32 && K >= 128) {
     const unsigned grid = (unsigned)(tiles < g_num_cu ? tiles : g_num_cu);
