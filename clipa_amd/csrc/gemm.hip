@@ -1792,9 +1792,16 @@ extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, co
 extern "C" int64_t clipa_gemm_tn_workspace(int64_t M, int64_t R, int64_t C, int64_t* nslices) {
   const long tiles = ((R + 255) / 256) * ((C + 255) / 256);
   const long mt = (M + 63) / 64;
-  long S = (1024 + tiles - 1) / tiles;     // aim for ~4 workgroups per CU
-  if (S > mt) S = mt;
+  // ~4 workgroups per CU, but never a thin last round: one workgroup per CU is resident (128 KiB LDS), so a grid of
+  // 4.1 x #CUs costs five rounds.  Take the largest slice count <= 64 whose grid fills >= 97 % of its rounds.
+  long S = (4L * g_num_cu) / tiles;
   if (S > 64) S = 64;
+  if (S < 1) S = 1;
+  for (long c = S; c >= 1; --c) {
+    const long w = tiles * c, rounds = (w + g_num_cu - 1) / g_num_cu;
+    if (w * 100 >= rounds * g_num_cu * 97 || c == 1) { if (w * 100 >= rounds * g_num_cu * 97) S = c; break; }
+  }
+  if (S > mt) S = mt;
   if (S < 1) S = 1;
   if (mt > 0) { const long per = (mt + S - 1) / S; S = (mt + per - 1) / per; }
   if (nslices) *nslices = S;
@@ -1819,10 +1826,10 @@ extern "C" int clipa_gemm_tn(const void* P, const void* Q, void* out, float* col
   a.colsum = colsum_out ? (float*)workspace + S * R * C : nullptr;
   const long tiles = ((R + 255) / 256) * ((C + 255) / 256);
   // ablation bit 9 (512) selects the first-generation kernel (one barrier per 64 rows, all waves in step)
-  // Default: the 16x16x32 first-generation schedule (v3) for wide-P products (R >= 4096: the c_fc weight gradient)
-  // and small square ones, the ping-pong kernel (v2) elsewhere - per-shape winners of tools/tn_ab.py, all within
+  // Default: the 16x16x32 first-generation schedule (v3) for the image tower's wide-P products (in-proj and c_fc
+  // weight gradients) and its 1024 x 1024 out-proj, the ping-pong kernel (v2) elsewhere (c_proj, the text tower) - per-shape winners of tools/tn_ab.py, all within
   // +-4 % except the text tower (v2 +18 %).  Ablation bits force one kernel: 512 v1, 1024 v3, 2048 v2.
-  const bool use_v3 = (g_abl & 1024) || (!(g_abl & (512 | 2048)) && (R >= 4096 || (R <= 1024 && C <= 1024)));
+  const bool use_v3 = (g_abl & 1024) || (!(g_abl & (512 | 2048)) && ((R >= 3072 && C >= 1024) || (R == 1024 && C == 1024)));
   if (use_v3) hipLaunchKernelGGL(gemm_tn3_kernel, dim3((unsigned)tiles, (unsigned)S), dim3(NTHREADS), 2 * STAGE_BYTES, (hipStream_t)stream, a);
   else if (g_abl & 512) hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)tiles, (unsigned)S), dim3(NTHREADS), 2 * STAGE_BYTES, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(gemm_tn2_kernel, dim3((unsigned)tiles, (unsigned)S), dim3(NTHREADS), 2 * STAGE_BYTES, (hipStream_t)stream, a);
