@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--keep-blocks", default="auto", help="'auto' or 'LV,LT[,MV,MT]': light-kept (and medium-kept) blocks per tower (image, text)")
     ap.add_argument("--keep-fraction", type=float, default=0.93, help="share of the free HBM 'auto' may spend")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shapes", action="store_true", help="also report time and TF/s per GEMM / attention shape (stderr)")
     ap.add_argument("--cpu-sample", type=int, default=8, help="pairs per CPU-baseline step")
     ap.add_argument("--cpu-timeout", type=int, default=240)
     args = ap.parse_args()
@@ -222,7 +223,7 @@ def main():
     for _ in range(warm):
         step()
     fence()
-    ops.profile_start()
+    ops.profile_start(detail=args.shapes)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -270,8 +271,13 @@ def main():
                          "launches": nt["launches"],
                          "avg_launch_ms": round(nt["ms"] / max(nt["launches"], 1), 4)},
             "kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 2),
-                            "tflops": round(v["work"] / max(v["ms"], 1e-9) / 1e9, 1)} for k, v in prof.items()},
+                            "tflops": round(v["work"] / max(v["ms"], 1e-9) / 1e9, 1)} for k, v in prof.items() if "|" not in k},
         }
+        if args.shapes:
+            for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+                if "|" in k:
+                    print(f"SHAPE {k:48s} n={v['launches'] // args.steps:4d}/step {v['ms'] / args.steps:8.2f} ms/step "
+                          f"{v['work'] / max(v['ms'], 1e-9) / 1e9:7.1f} TF/s", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             # bounded: run in a child process with a wall-clock limit so the bench line is never held hostage
             import subprocess

@@ -25,9 +25,10 @@ def _stream():
 _PROF = None
 
 
-def profile_start():
-    global _PROF
+def profile_start(detail=False):
+    global _PROF, _DETAIL
     _PROF = {}
+    _DETAIL = bool(detail)
 
 
 def profile_stop():
@@ -44,11 +45,14 @@ def profile_stop():
     return out
 
 
-class _Timed:
-    __slots__ = ("name", "work", "nbytes", "a")
+_DETAIL = False      # profile_start(detail=True): additionally key the records by shape ("gemm_nt|M,N,K,epi")
 
-    def __init__(self, name, work, nbytes=0.0):
-        self.name, self.work, self.nbytes = name, work, nbytes
+
+class _Timed:
+    __slots__ = ("name", "work", "nbytes", "a", "tag")
+
+    def __init__(self, name, work, nbytes=0.0, tag=None):
+        self.name, self.work, self.nbytes, self.tag = name, work, nbytes, tag
 
     def __enter__(self):
         if _PROF is not None:
@@ -60,6 +64,8 @@ class _Timed:
             b = torch.cuda.Event(enable_timing=True)
             b.record()
             _PROF.setdefault(self.name, []).append((self.a, b, self.work, self.nbytes))
+            if _DETAIL and self.tag is not None:
+                _PROF.setdefault(f"{self.name}|{self.tag}", []).append((self.a, b, self.work, self.nbytes))
         return False
 
 
@@ -108,7 +114,7 @@ def gemm_nt(a, b, bias=None, *, epi=EPI_NONE, act=ACT_GELU_ERF, aux=None, alpha=
         aux, ldaux = _rowmajor(aux)
     osz = 4 if out_f32 else 2
     nbytes = 2.0 * (M * K + N * K) + osz * M * N + (2.0 * M * N if aux is not None else 0) + (2.0 * M * N if want_pre else 0)
-    with _Timed("gemm_nt", 2.0 * M * N * K, nbytes):
+    with _Timed("gemm_nt", 2.0 * M * N * K, nbytes, f"{M},{N},{K},epi{epi}{'+pre' if want_pre else ''}{',f32' if out_f32 else ''}"):
         lib.call("clipa_gemm_nt", _p(a), _p(b), _p(out), _p(pre), _p(bias), _p(aux), M, N, K, lda, ldb, ldc, ldaux,
                  float(alpha), epi, act, 1 if out_f32 else 0, _stream())
     return (out, pre) if want_pre else out
@@ -129,7 +135,7 @@ def gemm_tn(p, q, out_dtype=f32, want_colsum=False):
     ws = torch.empty(max(wsb, 4) // 4, device=p.device, dtype=f32)
     out = torch.empty((R, C), device=p.device, dtype=out_dtype)
     cs = torch.empty(R, device=p.device, dtype=f32) if want_colsum else None
-    with _Timed("gemm_tn", 2.0 * M * R * C, 2.0 * M * (R + C) + out.element_size() * R * C):
+    with _Timed("gemm_tn", 2.0 * M * R * C, 2.0 * M * (R + C) + out.element_size() * R * C, f"{M},{R},{C}"):
         lib.call("clipa_gemm_tn", _p(p), _p(q), _p(out), _p(cs), M, R, C, ldp, ldq, 1 if out_dtype == bf16 else 0, _p(ws),
                  wsb, _stream())
     return (out, cs) if want_colsum else out
@@ -178,7 +184,7 @@ def attention_fwd(qkv, B, L, H, causal, want_stats=False):
     base = qkv.data_ptr()
     ld = qkv.stride(0)
     stats = torch.empty((B * H * L, 2), device=qkv.device, dtype=f32) if want_stats else None
-    with _Timed("attention_fwd", 4.0 * B * H * L * L * dh * (0.5 if causal else 1.0)):
+    with _Timed("attention_fwd", 4.0 * B * H * L * L * dh * (0.5 if causal else 1.0), 0.0, f"B{B},H{H},L{L},dh{dh}"):
         lib.call("clipa_attention_fwd", ctypes.c_void_p(base), ctypes.c_void_p(base + 2 * D),
                  ctypes.c_void_p(base + 4 * D), _p(out), _p(stats), B, H, L, dh, ld, D, 1.0 / math.sqrt(dh), int(causal),
                  _stream())
@@ -195,7 +201,7 @@ def attention_bwd(qkv, out, dout, stats, B, L, H, causal):
     dh = D // H
     dqkv = torch.empty_like(qkv)
     base, dbase = qkv.data_ptr(), dqkv.data_ptr()
-    with _Timed("attention_bwd", 10.0 * B * H * L * L * dh * (0.5 if causal else 1.0)):
+    with _Timed("attention_bwd", 10.0 * B * H * L * L * dh * (0.5 if causal else 1.0), 0.0, f"B{B},H{H},L{L},dh{dh}"):
         lib.call("clipa_attention_bwd", ctypes.c_void_p(base), ctypes.c_void_p(base + 2 * D),
                  ctypes.c_void_p(base + 4 * D), _p(out), _p(dout), _p(stats), ctypes.c_void_p(dbase), ctypes.c_void_p(dbase + 2 * D),
                  ctypes.c_void_p(dbase + 4 * D), B, H, L, dh, qkv.stride(0), D, dqkv.stride(0), 1.0 / math.sqrt(dh),
