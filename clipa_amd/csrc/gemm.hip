@@ -16,6 +16,21 @@
 // same XOR on the read (tools/lds_bank_sim.py).  gemm_tn reads its fragments with
 // ds_read_b64_tr_b16 (hardware transpose) because the reduction index is the slow axis of both
 // operands.  Tile ids are remapped so each XCD's L2 sees a contiguous run of tiles.
+//
+// Kernel generations in this file (clipa_debug_set / CLIPA_GEMM_NT pick one for in-process A/B runs; each is
+// covered by tests/test_kernels_gpu.py):
+//   gemm_nt_kernel        v1  one output tile per workgroup
+//   gemm_nt2_kernel       v2  persistent workgroups, DMA ring running across tiles; template flags: STAG = ping-pong
+//                             main loop (BK 32, four half-slots), M16 = v_mfma_f32_16x16x32_bf16 main loop + epilogue
+//                             -> <bf16, M16> is the PRODUCTION kernel for every bf16-output GEMM (variant 11);
+//                             <f32> serves the logits GEMMs
+//   gemm_nt3_kernel       v3  v2 + loader / storer wave roles (plain and fused epilogues)
+//   gemm_nt5_kernel       v5  ping-pong + roles, plain / bias epilogue
+//   gemm_tn_kernel        v1  split-M weight gradient, all waves in step
+//   gemm_tn2_kernel       v2  ping-pong schedule                      } production: chosen per shape by the host
+//   gemm_tn3_kernel       v3  v1 schedule on 16x16x32 MFMAs           }
+// Why so many: under the 1400 W power cap the schedules that stall less do not run faster, the ones that move
+// fewer register bytes per FLOP do - the older generations are kept as the measured baselines.
 #include "common.h"
 #include "clipa_hip.h"
 #include <cstdlib>
