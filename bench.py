@@ -39,6 +39,17 @@ def train_gflop_per_pair(cfg, S, ctx):
     return 3.0 * fwd / 1e9
 
 
+def plan_keep(budget, layers_v, layers_t, mv_b, mt_b, lv_b, lt_b):
+    """Spend `budget` bytes of HBM on kept activations where a byte saves the most recompute FLOPs: "medium" tier
+    first (image tower, then text), then upgrades medium -> "light".  -> (light_v, light_t, medium_v, medium_t)."""
+    budget = max(0, int(budget))
+    mv = min(layers_v, budget // mv_b); budget -= mv * mv_b
+    mt = min(layers_t, budget // mt_b); budget -= mt * mt_b
+    kv = min(mv, budget // (lv_b - mv_b)); budget -= kv * (lv_b - mv_b)
+    kt = min(mt, budget // (lt_b - mt_b))
+    return int(kv), int(kt), int(mv - kv), int(mt - kt)
+
+
 def usable_cores(cap=64):
     """Host cores this process may really use: affinity mask and cgroup CPU quota, capped (an OpenMP team far
     larger than the quota spin-waits and is slower than a small one)."""
@@ -194,11 +205,7 @@ def main():
         lv_b, lt_b = vt.light_keep_bytes(B * L_img), tt.light_keep_bytes(B * args.ctx)
 
         def plan(budget):
-            mv = max(0, min(cfg["vision_cfg"]["layers"], budget // mv_b)); budget -= mv * mv_b
-            mt = max(0, min(cfg["text_cfg"]["layers"], budget // mt_b)); budget -= mt * mt_b
-            kv = max(0, min(mv, budget // (lv_b - mv_b))); budget -= kv * (lv_b - mv_b)
-            kt = max(0, min(mt, budget // (lt_b - mt_b)))
-            return int(kv), int(kt), int(mv - kv), int(mt - kt)
+            return plan_keep(budget, cfg["vision_cfg"]["layers"], cfg["text_cfg"]["layers"], mv_b, mt_b, lv_b, lt_b)
 
         keep_v, keep_t, med_v, med_t = plan(budget0)
         if world == 1:

@@ -152,3 +152,23 @@ def test_bench_flop_accounting_matches_survey_table():
         got = bench.train_gflop_per_pair(clipa_amd.get_model_config(name), S, ctx)
         assert abs(got - gf) <= 0.01 * gf, (name, S, ctx, got, gf)
     assert 1 <= bench.usable_cores() <= 64
+
+
+def test_bench_keep_planner_respects_the_budget():
+    import bench
+    m = clipa_amd.create_model("ViT-L-16")
+    tokens_v, tokens_t = 4096 * 197, 4096 * 77
+    mv, mt = m.visual.transformer.medium_keep_bytes(tokens_v), m.transformer.medium_keep_bytes(tokens_t)
+    lv, lt = m.visual.transformer.light_keep_bytes(tokens_v), m.transformer.light_keep_bytes(tokens_t)
+    assert lv > mv > 0 and lt > mt > 0
+    prev = -1
+    for gb in (0, 5, 50, 100, 166, 250, 400, 2000):
+        kv, kt, dv, dt = bench.plan_keep(gb << 30, 24, 12, mv, mt, lv, lt)
+        used = kv * lv + dv * mv + kt * lt + dt * mt
+        assert used <= (gb << 30) and kv + dv <= 24 and kt + dt <= 12
+        saved = 25.5 * kv + 17.5 * dv          # recompute units avoided in the image tower
+        assert saved >= prev
+        prev = saved
+    kv, kt, dv, dt = bench.plan_keep(200 << 30, 24, 12, mv, mt, lv, lt)
+    assert (kv, kt, dv) == (0, 0, 24) and 1 <= dt <= 12            # medium everywhere in the image tower before any upgrade
+    assert bench.plan_keep(2000 << 30, 24, 12, mv, mt, lv, lt) == (24, 12, 0, 0)
