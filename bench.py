@@ -126,7 +126,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    # CLIPA_BENCH_FORCE_DIST=1 (under torchrun --nproc-per-node 1) walks the multi-rank code path - RCCL process
+    # group, DDP wrapper, barriers, max-over-ranks reduction - on a single GPU: a pre-flight for the scaling runs
+    dist_on = world > 1 or os.environ.get("CLIPA_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
 
@@ -150,7 +153,7 @@ def main():
                  {"params": [p for n, p in named if not exclude(n, p) and p.requires_grad], "weight_decay": 0.2}],
                 lr=5e-4, betas=(0.9, 0.95), eps=1e-6)
     step_model = model
-    if world > 1:
+    if dist_on:
         step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], static_graph=True)
     loss_fn = clipa_amd.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True, rank=rank, world_size=world)
 
@@ -176,7 +179,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -238,7 +241,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ops.profile_stop()
     last_loss = float(loss)
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
@@ -304,7 +307,7 @@ def main():
                 line["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": threads, "kind": "port",
                                         "sample": f"timed out after {args.cpu_timeout}s ({args.cpu_sample} pairs/step)"}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 
