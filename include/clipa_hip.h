@@ -40,14 +40,11 @@ extern "C" {
 
 const char* clipa_last_error(void);
 int clipa_version(void);
-/* kernel-experiment hook (tools/gemm_ab.py, tools/tn_ab.py; in-process A/B of kernel generations).  gemm_nt
- * variant: 1 one tile per workgroup; 2 persistent tiles; 3 = 2 + s_setprio; 5 loader/storer wave roles
- * for plain/bias epilogues, 3 for fused ones; 6 roles for every epilogue; 7 ping-pong main loop; 8 = 7 for fused
- * epilogues, roles for plain; 9 ping-pong + roles (gemm_nt5) for plain, 7 for fused;
- * 10 16x16x32 MFMAs in the persistent ring for fused epilogues, roles for plain; 11 (default) 16x16x32 for every
- * bf16-output GEMM.  Ablation bit flags: 1 no
- * global stores, 2 no epilogue, 4 no bias, 8 row-major tile order, 16 spread DMA issue, 32 alias stores into
- * 256 rows, 512 / 1024 / 2048 force gemm_tn v1 / v3 / v2.  Production callers never touch it. */
+/* kernel-experiment hook (tools/gemm_round2.py, tools/tn_ab.py, tests: in-process A/B of kernels; two relaxed atomics).
+ * gemm_nt variant: 0 (default) per-epilogue routing; 11 LDS-window epilogue for every bf16-output GEMM; 12 direct
+ * (MFMA-fragment-layout) epilogue for every bf16-output GEMM.  Flags: 1 epilogue maths without global stores, 2 main
+ * loop only, 8 row-major tile order; gemm_tn: 1024 / 2048 force the 16x16x32 / ping-pong kernel, 4096 / 8192 force
+ * the slice-per-XCD / tile-per-XCD work order.  Production callers never touch it. */
 int clipa_debug_set(int gemm_nt_variant, int ablation_flags);
 
 /* C[M,N] = epi(alpha * A[M,K] . B[N,K]^T + bias[N]); A,B bf16; C bf16 (or f32 when out_f32, epi NONE).

@@ -124,3 +124,23 @@ def attn_check():
 
 if __name__ == "__main__":
     attn_check()
+
+
+def nt6_check():
+    """gemm_nt6 images: 64-byte rows (4 chunks), physical chunk = logical ^ ((-(row>>2)) & 3); 16x16x32 fragment read:
+    lane (c = l & 15, g = l >> 4) -> row r0 + c, logical chunk g."""
+    print("gemm_nt6 64-B-row image, 16x16x32 fragment reads (ideal 4 cycles):")
+    for name, f in (("swizzled", lambda row: (0 - (row >> 2)) & 3), ("linear", lambda row: 0)):
+        worst = 0
+        for r0 in range(0, 256, 16):
+            addrs = []
+            for l in range(64):
+                c, g = l & 15, l >> 4
+                row = r0 + c
+                addrs.append(row * 64 + ((g ^ f(row)) << 4))
+            worst = max(worst, read_b128(addrs))
+        print(f"  {name}: worst {worst}")
+
+
+if __name__ == "__main__":
+    nt6_check()
