@@ -5,12 +5,19 @@ Drop-in for `open_clip.loss.ClipLoss` (clipa_torch/open_clip/loss.py:92-157) and
 `loss(image_features, text_features, logit_scale, output_dict=False)`, same variants
 (local_loss x gather_with_grad), same label convention (arange + B*rank, loss.py:115-126).
 
-MI355X mapping: the image and text embeddings of a rank travel as ONE fused [B, 2E] bf16 message in a
-single RCCL all-gather (torch.distributed backend "nccl" is RCCL on ROCm; xGMI underneath), issued on
-a side HIP stream so it can overlap with whatever the compute stream still has queued; the backward of
-the differentiable gather is one reduce-scatter(SUM) of the fused [W*B, 2E] gradient, which is the
-semantics of torch.distributed.nn.all_gather's backward used by the reference.  Logits, the
-row-softmax cross-entropy and all four gradient GEMMs run in libclipa_hip.so.
+MI355X mapping.
+* Gather: each rank's embeddings travel as bf16 over RCCL (torch.distributed backend "nccl" is RCCL on ROCm; xGMI
+  underneath) on a side HIP stream.  The IMAGE embeddings are gathered EARLY: `CLIP.forward` hands them to
+  `early_gather()` as soon as the image tower's projection + normalisation are done, so the all-gather runs
+  concurrently with the whole text tower on the compute stream; the loss picks the result up (`_PENDING`) and only
+  the text gather is exposed.  (The reference gathers both serially after both towers, loss.py:73-76.)
+* Backward of the differentiable gather = ONE reduce-scatter(SUM) of the fused [W*B, 2E] fp32 gradient - the
+  semantics of torch.distributed.nn.all_gather's backward used by the reference.
+* The similarity GEMMs produce the UNSCALED I.T^T; exp(logit_scale) stays in device memory and is applied inside the
+  cross-entropy kernel (`ops.ce_rows(scale=...)`), which also folds it into the bf16 d loss / d raw the four gradient
+  GEMMs consume - no `.item()`, no host sync per step.  Batches that are not multiples of 8 are zero-padded to the
+  GEMM granularity; the pad columns are excluded from the softmax inside the kernel.
+* Host-side glue that stays in torch: `torch.cat` / `+` of the [B, E] gradient pieces in backward (a few MB).
 """
 import torch
 import torch.distributed as dist
@@ -20,22 +27,53 @@ from . import ops
 
 bf16, f32 = torch.bfloat16, torch.float32
 
+_SIDE = {}
+_EARLY = {"world_size": 1, "group": None}     # set by ClipLoss.__init__ when world_size > 1
+_PENDING = {}                                 # feature data_ptr -> (local bf16, gathered bf16, side-stream event)
 
-def _gather_fused(local, world_size, group=None):
-    """all-gather [B, 2E] bf16 -> [W*B, 2E] on a side stream (overlaps with queued compute)."""
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
+def _all_gather_bf16(local, world_size, group=None):
+    """all-gather [B, E] bf16 -> [W*B, E], issued on the side stream; returns (gathered, event | None).  The caller's
+    stream must wait for the event before it reads `gathered`."""
     out = torch.empty((world_size * local.shape[0], local.shape[1]), device=local.device, dtype=local.dtype)
     if local.is_cuda:
         cur = torch.cuda.current_stream()
         side = _side_stream(local.device)
-        side.wait_stream(cur)
+        side.wait_stream(cur)                         # `local` was produced on the compute stream
         with torch.cuda.stream(side):
             dist.all_gather_into_tensor(out.view(torch.uint8), local.view(torch.uint8), group=group)   # pure byte movement
-        cur.wait_stream(side)
+            ev = torch.cuda.Event()
+            ev.record(side)
         local.record_stream(side)
         out.record_stream(side)
-    else:
-        dist.all_gather_into_tensor(out, local, group=group)
-    return out
+        return out, ev
+    dist.all_gather_into_tensor(out, local, group=group)
+    return out, None
+
+
+def early_gather(features):
+    """Called by CLIP.forward right after the image tower: start the all-gather of the (normalised, f32 [B, E]) image
+    features on the side stream so that it overlaps the text tower.  No-op unless a multi-rank ClipLoss exists."""
+    W = _EARLY["world_size"]
+    if W <= 1 or not dist.is_available() or not dist.is_initialized():
+        return
+    local = ops.to_bf16(features.detach())
+    gathered, ev = _all_gather_bf16(local, W, _EARLY["group"])
+    _PENDING.clear()                                  # at most one step in flight
+    _PENDING[features.data_ptr()] = (local, gathered, ev)
+
+
+def _take_pending(features):
+    ent = _PENDING.pop(features.data_ptr(), None)
+    _PENDING.clear()
+    return ent
 
 
 def _reduce_scatter_fused(full, world_size, group=None):
@@ -51,14 +89,15 @@ def _reduce_scatter_fused(full, world_size, group=None):
     return out
 
 
-_SIDE = {}
-
-
-def _side_stream(device):
-    key = (device.type, device.index)
-    if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=device)
-    return _SIDE[key]
+def _pad_rows8(x):
+    """[n, E] -> [n8, E] with zero rows (the similarity GEMMs need N, and their gradients K, in multiples of 8)."""
+    n = x.shape[0]
+    n8 = (n + 7) // 8 * 8
+    if n8 == n:
+        return x
+    out = torch.zeros((n8, x.shape[1]), device=x.device, dtype=x.dtype)
+    out[:n] = x
+    return out
 
 
 class ClipLossFn(torch.autograd.Function):
@@ -67,64 +106,75 @@ class ClipLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, txt, logit_scale, local_loss, gather_with_grad, rank, world_size, group):
         B, E = img.shape
-        s_t = logit_scale.detach().to(f32).reshape(())
-        s = float(s_t.item())   # scalar needed as the GEMM alpha (host sync of one 4-byte value)
-        ib, tb = ops.to_bf16(img), ops.to_bf16(txt)
+        s_dev = logit_scale.detach().to(f32).reshape(1).contiguous()     # stays on the device
+        pend = _take_pending(img) if world_size > 1 else None
+        tb = ops.to_bf16(txt)
         if world_size > 1:
-            fused = torch.cat([ib, tb], dim=1)
-            allf = _gather_fused(fused, world_size, group)
-            i_all, t_all = allf[:, :E], allf[:, E:]
+            t_all, t_ev = _all_gather_bf16(tb, world_size, group)
+            if pend is not None:
+                ib, i_all, i_ev = pend                                    # started before the text tower ran
+            else:
+                ib = ops.to_bf16(img)
+                i_all, i_ev = _all_gather_bf16(ib, world_size, group)
+            if img.is_cuda:
+                cur = torch.cuda.current_stream()
+                for ev in (i_ev, t_ev):
+                    if ev is not None:
+                        cur.wait_event(ev)
         else:
+            ib = ops.to_bf16(img)
             i_all, t_all = ib, tb
         if world_size > 1 and not local_loss:
             i_rows, t_rows, label0 = i_all, t_all, 0
         else:
             i_rows, t_rows, label0 = ib, tb, (B * rank if world_size > 1 else 0)
-        R = i_rows.shape[0]
-        logits_i = ops.gemm_nt(i_rows, t_all, alpha=s, out_f32=True)      # [R, W*B]
-        logits_t = ops.gemm_nt(t_rows, i_all, alpha=s, out_f32=True)
+        R, N = i_rows.shape[0], i_all.shape[0]
+        i_all8, t_all8 = _pad_rows8(i_all), _pad_rows8(t_all)
+        raw_i = ops.gemm_nt(i_rows, t_all8, out_f32=True)                 # [R, N8] unscaled similarities
+        raw_t = ops.gemm_nt(t_rows, i_all8, out_f32=True)
         need_grad = any(ctx.needs_input_grad[:3])
         gs = 0.5 / R
-        li, dli, dsi = ops.ce_rows(logits_i, label0, gs, want_grad=need_grad)
-        lt, dlt, dst = ops.ce_rows(logits_t, label0, gs, want_grad=need_grad)
+        li, dli, dsi = ops.ce_rows(raw_i, N, label0, gs, scale=s_dev, want_grad=need_grad)
+        lt, dlt, dst = ops.ce_rows(raw_t, N, label0, gs, scale=s_dev, want_grad=need_grad)
         loss = ops.sum_scale(li, gs)
         ops.sum_scale(lt, gs, out=loss, accumulate=True)
         if need_grad:
-            ctx.save_for_backward(dli, dlt, dsi, dst, i_rows, t_rows, i_all, t_all)
-            ctx.meta = (s, B, E, local_loss, gather_with_grad, rank, world_size, group, img.dtype, txt.dtype,
-                        logit_scale.dtype)
+            ctx.save_for_backward(dli, dlt, dsi, dst, i_rows, t_rows, i_all8, t_all8)
+            ctx.meta = (B, E, N, local_loss, gather_with_grad, rank, world_size, group, img.dtype, txt.dtype,
+                        logit_scale.dtype, logit_scale.shape)
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
-        dli, dlt, dsi, dst, i_rows, t_rows, i_all, t_all = ctx.saved_tensors
-        s, B, E, local_loss, gather_with_grad, rank, W, group, idt, tdt, sdt = ctx.meta
-        # d/d(rows): logits_i = s I_rows T_all^T ; logits_t = s T_rows I_all^T
-        d_i_rows = ops.gemm_nt(dli, ops.transpose_bf16(t_all), alpha=s, out_f32=True)     # [R,E]
-        d_t_rows = ops.gemm_nt(dlt, ops.transpose_bf16(i_all), alpha=s, out_f32=True)
+        dli, dlt, dsi, dst, i_rows, t_rows, i_all8, t_all8 = ctx.saved_tensors
+        B, E, N, local_loss, gather_with_grad, rank, W, group, idt, tdt, sdt, sshape = ctx.meta
+        # dli / dlt = d loss / d raw (the scale is already folded in).  raw_i = I_rows T_all^T ; raw_t = T_rows I_all^T
+        d_i_rows = ops.gemm_nt(dli, ops.transpose_bf16(t_all8), out_f32=True)              # [R, E]
+        d_t_rows = ops.gemm_nt(dlt, ops.transpose_bf16(i_all8), out_f32=True)
         # d/d(gathered columns)
-        d_t_all = ops.gemm_tn(dli, i_rows, f32)                                            # [W*B,E]
-        d_i_all = ops.gemm_tn(dlt, t_rows, f32)
+        d_t_all = ops.gemm_tn(dli, i_rows, f32)[:N]                                        # [W*B, E]
+        d_i_all = ops.gemm_tn(dlt, t_rows, f32)[:N]
         if W == 1:
-            d_i = d_i_rows + s * d_i_all
-            d_t = d_t_rows + s * d_t_all
+            d_i = d_i_rows + d_i_all
+            d_t = d_t_rows + d_t_all
         elif local_loss:
             d_i, d_t = d_i_rows, d_t_rows
             if gather_with_grad:
-                rs = _reduce_scatter_fused(torch.cat([d_i_all, d_t_all], dim=1) * s, W, group)
+                rs = _reduce_scatter_fused(torch.cat([d_i_all, d_t_all], dim=1), W, group)
                 d_i = d_i + rs[:, :E]
                 d_t = d_t + rs[:, E:]
         else:
             # rows are the gathered features themselves: every term is a gradient w.r.t. the gather
-            full = torch.cat([d_i_rows + s * d_i_all, d_t_rows + s * d_t_all], dim=1)
+            full = torch.cat([d_i_rows + d_i_all, d_t_rows + d_t_all], dim=1)
             if gather_with_grad:
                 rs = _reduce_scatter_fused(full, W, group)
             else:
                 rs = full[rank * B:(rank + 1) * B]      # only the re-inserted local slice carries grad
             d_i, d_t = rs[:, :E], rs[:, E:]
-        d_s = (ops.sum_scale(dsi, 1.0 / s) + ops.sum_scale(dst, 1.0 / s)).reshape(())
+        d_s = ops.sum_scale(dsi, 1.0)
+        ops.sum_scale(dst, 1.0, out=d_s, accumulate=True)
         g = dloss.to(f32)
-        return ((d_i * g).to(idt), (d_t * g).to(tdt), (d_s * g).to(sdt), None, None, None, None, None)
+        return ((d_i * g).to(idt), (d_t * g).to(tdt), (d_s * g).to(sdt).reshape(sshape), None, None, None, None, None)
 
 
 class ClipLoss(nn.Module):
@@ -142,6 +192,8 @@ class ClipLoss(nn.Module):
         self.world_size = world_size
         self.use_horovod = use_horovod
         self.group = group
+        # a multi-rank loss object exists: let CLIP.forward start the image-feature gather before the text tower
+        _EARLY["world_size"], _EARLY["group"] = world_size, group
 
     def forward(self, image_features, text_features, logit_scale, output_dict=False):
         if not torch.is_tensor(logit_scale):

@@ -353,6 +353,12 @@ class CLIP(nn.Module):
 
     def forward(self, image, text):
         image_features = self.encode_image(image, normalize=True)
+        if self.training and torch.is_grad_enabled():
+            # MI355X engine: if a multi-rank ClipLoss exists, the RCCL all-gather of the image embeddings starts now,
+            # on a side stream, and runs under the text tower (clipa_amd.loss.early_gather; north_star: "overlapped
+            # ... on a side HIP stream").  Single-rank / eval: no-op.
+            from . import loss as _loss
+            _loss.early_gather(image_features)
         text_features = self.encode_text(text, normalize=True)
         if self.output_dict:
             return {"image_features": image_features, "text_features": text_features,

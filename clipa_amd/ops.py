@@ -361,14 +361,21 @@ def activation_fwd(x, act):
     return out
 
 
-def ce_rows(logits, label0, gscale, want_grad=True):
-    """Row-wise CE with labels label0 + row. Returns loss_rows f32 [R], dlogits bf16 [R,N] | None, dscale_rows."""
-    _chk(logits, f32, "logits", 2)
-    R, N = logits.shape
-    loss_rows = torch.empty(R, device=logits.device, dtype=f32)
-    dscale_rows = torch.empty(R, device=logits.device, dtype=f32)
-    dl = torch.empty((R, N), device=logits.device, dtype=bf16) if want_grad else None
-    lib.call("clipa_ce_rows", _p(logits), R, N, logits.stride(0), label0, float(gscale), _p(dl), N, _p(loss_rows),
+def ce_rows(raw, n_valid, label0, gscale, scale=None, want_grad=True):
+    """Row-wise CE of s * raw[:, :n_valid] with labels label0 + row; s = scale[0] read on the device (None = 1).
+    raw f32 [R, ld] with ld >= n_valid rounded up to 8.  Returns loss_rows f32 [R], d loss / d raw bf16 [R, ld8]
+    (pad columns zero) | None, and the per-row d loss / d s."""
+    _chk(raw, f32, "raw", 2)
+    R = raw.shape[0]
+    n8 = (n_valid + 7) // 8 * 8
+    if raw.stride(0) < n8:
+        raise RuntimeError(f"ce_rows: row stride {raw.stride(0)} < {n8}")
+    loss_rows = torch.empty(R, device=raw.device, dtype=f32)
+    dscale_rows = torch.empty(R, device=raw.device, dtype=f32)
+    dl = torch.empty((R, n8), device=raw.device, dtype=bf16) if want_grad else None
+    if scale is not None:
+        _chk(scale, f32, "scale")
+    lib.call("clipa_ce_rows", _p(raw), R, n_valid, raw.stride(0), label0, float(gscale), _p(scale), _p(dl), n8, _p(loss_rows),
              _p(dscale_rows), _stream())
     return loss_rows, dl, dscale_rows
 

@@ -120,10 +120,14 @@ int clipa_transpose_to_bf16(const void* in, int in_f32, void* out, int64_t R, in
                             int64_t ldo, void* stream);
 /* out = act(in) elementwise, bf16 (MLP activation re-materialised from the kept pre-activation) */
 int clipa_activation_fwd(const void* in, void* out, int64_t n, int act, void* stream);
-/* F.cross_entropy(logits, arange + label0) rows (loss.py:115-126,152-155): per-row loss, bf16 gradient
- * gscale*(softmax - onehot) and per-row sum_j dlogits_j*logits_j (for d/d logit_scale). */
-int clipa_ce_rows(const float* logits, int64_t rows, int64_t N, int64_t ld, int64_t label0, float gscale,
-                  void* dlogits_bf16, int64_t ldd, float* loss_rows, float* dscale_rows, void* stream);
+/* F.cross_entropy(s * raw, arange + label0) rows (loss.py:115-126,152-155) on the UNSCALED similarities raw = I.T^T:
+ * the scale s = exp(logit_scale) is read from device memory (`scale`, may be NULL = 1), so the loss never syncs the
+ * host.  Only the first N columns of a row exist (ld, ldd >= N rounded up to 8: the GEMMs want multiples of 8).
+ * Outputs: per-row loss; bf16 d loss / d raw = s * gscale * (softmax - onehot), pad columns zeroed; per-row
+ * d loss / d s = sum_j gscale * (softmax - onehot)_j * raw_j. */
+int clipa_ce_rows(const float* raw, int64_t rows, int64_t N, int64_t ld, int64_t label0, float gscale,
+                  const float* scale, void* dlogits_bf16, int64_t ldd, float* loss_rows, float* dscale_rows,
+                  void* stream);
 int clipa_sum_scale(const float* in, float* out, int64_t n, float scale, int accumulate, void* stream);
 
 /* AdamW over one flat tensor (training/main.py:318-326 torch.optim.AdamW + train.py:285-286 clamp is

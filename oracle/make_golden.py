@@ -53,6 +53,27 @@ CASES = {
 }
 
 
+# Full model dimensions (SURVEY 8c "planned oracle artefacts"): the reference's own model_configs/*.json at BASELINE
+# shapes, small batch.  cfg is read from the reference's JSON at generation time and stored in the fixture.
+FULL_CASES = {
+    "full_L16_224": dict(json="ViT-L-16.json", B=4, S=224, seed=21),                 # BASELINE configs 3 / 5b
+    "full_B16_224": dict(json="ViT-B-16.json", B=4, S=224, seed=22),                 # BASELINE config 2
+    "full_H14_224": dict(json="ViT-H-14.json", B=2, S=224, seed=23),                 # BASELINE config 4 (head dim 80)
+    "full_L16_84_gap": dict(json="ViT-L-16-CL32-GAP.json", B=4, S=84, seed=24, ctx=77,   # BASELINE config 5a: 26 tokens,
+                            vision_extra={"pos_embed": "sin_cos_2d"}),                   # GAP, frozen sin-cos table
+}
+
+
+def full_cfg(spec):
+    path = os.path.join(ref_loader.REF_ROOT, "open_clip", "model_configs", spec["json"])
+    cfg = json.load(open(path))
+    cfg["vision_cfg"]["image_size"] = spec["S"]
+    cfg["vision_cfg"].update(spec.get("vision_extra", {}))
+    if "ctx" in spec:
+        cfg["text_cfg"]["context_length"] = spec["ctx"]
+    return cfg
+
+
 def grad_digest(named_grads, seed):
     names = sorted(named_grads)
     rng = np.random.RandomState(seed)
@@ -155,6 +176,9 @@ def main():
     for name, spec in CASES.items():
         if not only or name in only:
             run_case(name, spec, ref_model, ref_loss)
+    for name, spec in FULL_CASES.items():
+        if not only or name in only or "full" in only:
+            run_case(name, dict(spec, cfg=full_cfg(spec)), ref_model, ref_loss)
     if not only or "dist_loss_w2" in only:
         run_dist()
 

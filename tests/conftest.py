@@ -11,6 +11,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 MODEL_CASES = ["cls_erf", "gap_sincos_tanh", "bigvision_quick", "h14_dh80"]
+# full model dimensions at BASELINE shapes (ViT-L/16, ViT-B/16, ViT-H/14 @ 224 + text-77; ViT-L/16 @ 84 GAP / sin-cos),
+# generated from the reference's own model_configs/*.json by oracle/make_golden.py
+FULL_CASES = ["full_B16_224", "full_L16_224", "full_H14_224", "full_L16_84_gap"]
 
 
 def pytest_configure(config):
@@ -52,6 +55,11 @@ class Golden:
 
 @pytest.fixture(params=MODEL_CASES)
 def golden(request):
+    return Golden(request.param)
+
+
+@pytest.fixture(params=FULL_CASES)
+def golden_full(request):
     return Golden(request.param)
 
 

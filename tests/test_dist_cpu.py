@@ -1,4 +1,4 @@
-"""world_size-2 gloo test (CPU) of the multi-rank glue of clipa_amd.loss: fused [B,2E] all-gather,
+"""world_size-2 gloo test (CPU) of the multi-rank glue of clipa_amd.loss: bf16 feature all-gathers,
 label offsets, the four local_loss x gather_with_grad variants and the reduce-scatter backward - checked
 against tests/golden/dist_loss_w2.npz, which was produced by the REAL reference ClipLoss under a 2-rank
 gloo group.  The HIP kernels cannot run here, so - in this test process only - `clipa_amd.loss.ops` is
@@ -23,15 +23,21 @@ def _cpu_ops():
     o.gemm_nt = lambda a, b, alpha=1.0, out_f32=True: (a.float() @ b.float().T) * alpha
     o.gemm_tn = lambda p, q, dt=f32: (p.float().T @ q.float()).to(dt)
 
-    def ce_rows(logits, label0, gscale, want_grad=True):
-        R, N = logits.shape
+    def ce_rows(raw, n_valid, label0, gscale, scale=None, want_grad=True):
+        R = raw.shape[0]
+        n8 = (n_valid + 7) // 8 * 8
+        s = float(scale.reshape(-1)[0]) if scale is not None else 1.0
+        logits = raw[:, :n_valid].float() * s
         labels = torch.arange(R) + label0
-        lse = torch.logsumexp(logits, dim=1)
-        loss_rows = lse - logits[torch.arange(R), labels]
+        loss_rows = torch.logsumexp(logits, dim=1) - logits[torch.arange(R), labels]
         p = torch.softmax(logits, dim=1)
         p[torch.arange(R), labels] -= 1.0
         g = p * gscale
-        return loss_rows, (g.to(bf16) if want_grad else None), (g * logits).sum(1)
+        dl = None
+        if want_grad:
+            dl = torch.zeros((R, n8), dtype=bf16)
+            dl[:, :n_valid] = (g * s).to(bf16)
+        return loss_rows, dl, (g * raw[:, :n_valid].float()).sum(1)
 
     def sum_scale(x, scale, out=None, accumulate=False):
         v = x.sum() * scale

@@ -351,16 +351,21 @@ def test_assemble_embed_pool_l2norm_colsum_cast():
 
 @pytest.mark.parametrize("R,N,label0", [(8, 8, 0), (16, 64, 48), (300, 4096, 1000)])
 def test_cross_entropy_rows(R, N, label0):
-    logits = rnd(R, N, seed=80, dtype=f32, scale=4.0)
-    lr = logits.double().requires_grad_(True)
+    """logits = s * raw with the scale in device memory; N need not be a multiple of 8 (pad columns are ignored)."""
+    n8 = (N + 7) // 8 * 8
+    raw = rnd(R, n8, seed=80, dtype=f32, scale=0.3)
+    s = 13.7
+    lr = (raw[:, :N].double() * s).requires_grad_(True)
     labels = torch.arange(R) + label0
     per = torch.nn.functional.cross_entropy(lr, labels, reduction="none")
     gs = 0.5 / R
     (per.sum() * gs).backward()
-    loss_rows, dl, ds = ops().ce_rows(logits.to(DEV), label0, gs)
-    check("loss rows", loss_rows, per, 1e-5, 1e-5)
-    check("dlogits", dl, lr.grad, 2 ** -7, 1e-7)
-    check("dscale rows", ds, (lr.grad * logits.double()).sum(1), 1e-3, 1e-4)
+    scale = torch.tensor([s], device=DEV, dtype=f32)
+    loss_rows, dl, ds = ops().ce_rows(raw.to(DEV), N, label0, gs, scale=scale)
+    check("loss rows", loss_rows, per, 1e-5, 2e-5)
+    check("d loss / d raw", dl[:, :N], lr.grad * s, 2 ** -7, 1e-7)
+    assert not dl[:, N:].float().abs().any(), "pad columns of the gradient must be zero"
+    check("d loss / d s rows", ds, (lr.grad * raw[:, :N].double()).sum(1), 1e-3, 1e-5)
     check("sum", ops().sum_scale(loss_rows, gs), per.sum() * gs, 1e-5, 1e-6)
 
 

@@ -50,7 +50,22 @@ def _step(m, g, images=None):
 
 
 def test_forward_loss_match_reference_golden(golden):
-    g = golden
+    _check_forward_loss(golden)
+
+
+def test_full_dims_forward_loss_match_reference_golden(golden_full):
+    """BASELINE model dimensions (ViT-L/16, B/16, H/14 @ 224 + text-77; L/16 @ 84 GAP), batch 2-4: features, logit scale
+    and loss of the real reference (fp32) - same stated tolerance as the toy-dimension goldens."""
+    _check_forward_loss(golden_full)
+
+
+def test_full_dims_parameter_gradients_match_oracle(golden_full):
+    """Every parameter gradient of the 12- to 32-layer models against the fp32 oracle, whose gradients are pinned to
+    the reference's digests inside the same test."""
+    _check_gradients(golden_full)
+
+
+def _check_forward_loss(g):
     m = _engine(g)
     out, loss = _step(m, g)
     i, t = out["image_features"].float().cpu(), out["text_features"].float().cpu()
@@ -67,7 +82,10 @@ def test_forward_loss_match_reference_golden(golden):
 
 
 def test_all_parameter_gradients_match_oracle(golden):
-    g = golden
+    _check_gradients(golden)
+
+
+def _check_gradients(g):
     ref_loss, ref = _oracle_grads(g)
     m = _engine(g)
     _step(m, g)
@@ -84,11 +102,18 @@ def test_all_parameter_gradients_match_oracle(golden):
         if nb < 1e-7:
             assert float(a.norm()) < 1e-5, n
             continue
+        if a.numel() == 1:
+            # logit_scale: ONE number that is a sum of cancelling terms sum_ij (p_ij - delta_ij) * raw_ij / 2B; with
+            # bf16 embeddings (|err| ~ 2e-3 per dot product) and a batch of 2-4 its absolute error is ~ 5e-3
+            # whatever its size - stated tolerance: 5 % or 6e-3 absolute, and the right sign
+            assert abs(float(a) - float(b)) <= max(0.05 * nb, 6e-3), f"{n}: {float(a):.5f} vs {float(b):.5f}"
+            assert float(a) * float(b) > 0 or nb < 6e-3, n
+            continue
         cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
         worst = min(worst, (cos, n))
         assert cos > 0.99, f"{n}: cosine {cos:.5f}"
         assert abs(float(a.norm()) / nb - 1.0) < 0.05, f"{n}: norm ratio {float(a.norm()) / nb:.4f}"
-    print("worst gradient cosine:", worst)
+    print(f"[{g.name}] worst gradient cosine:", worst)
 
 
 def test_recompute_equals_stored_activations(golden):
