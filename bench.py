@@ -50,6 +50,15 @@ def plan_keep(budget, layers_v, layers_t, mv_b, mt_b, lv_b, lt_b):
     return int(kv), int(kt), int(mv - kv), int(mt - kt)
 
 
+def agree_budget(budget, device):
+    """Every rank must keep the SAME blocks (identical collectives, identical step time; a rank that keeps more can run
+    out of HBM alone): all ranks adopt the smallest activation budget any of them measured."""
+    import torch.distributed as dist
+    bt = torch.tensor([int(budget)], device=device, dtype=torch.int64)
+    dist.all_reduce(bt, op=dist.ReduceOp.MIN)
+    return int(bt.item())
+
+
 def usable_cores(cap=64):
     """Host cores this process may really use: affinity mask and cgroup CPU quota, capped (an OpenMP team far
     larger than the quota spin-waits and is slower than a small one)."""
@@ -107,7 +116,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "amp_bf16"],
                     help="bf16 = reference 'bf16' mode (bf16 weights); amp_bf16 = fp32 master weights")
     ap.add_argument("--keep-blocks", default="auto", help="'auto' or 'LV,LT[,MV,MT]': light-kept (and medium-kept) blocks per tower (image, text)")
-    ap.add_argument("--keep-fraction", type=float, default=0.93, help="share of the free HBM 'auto' may spend")
+    ap.add_argument("--keep-fraction", type=float, default=None,
+                    help="share of the free HBM 'auto' may spend (default 0.93 single process, 0.86 with several ranks: no OOM back-off there)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shapes", action="store_true", help="also report time and TF/s per GEMM / attention shape (stderr)")
     ap.add_argument("--cpu-sample", type=int, default=8, help="pairs per CPU-baseline step")
@@ -136,7 +146,6 @@ def main():
     import clipa_amd
     from clipa_amd import ops
     from clipa_amd.optim import AdamW
-    from oracle import clip_oracle as O
 
     cfg = clipa_amd.get_model_config(args.model)
     cfg["vision_cfg"]["image_size"] = args.image_size
@@ -151,30 +160,24 @@ def main():
     exclude = lambda n, p: p.ndim < 2 or "bn" in n or "ln" in n or "bias" in n or "logit_scale" in n   # main.py:311-316
     opt = AdamW([{"params": [p for n, p in named if exclude(n, p) and p.requires_grad], "weight_decay": 0.},
                  {"params": [p for n, p in named if not exclude(n, p) and p.requires_grad], "weight_decay": 0.2}],
-                lr=5e-4, betas=(0.9, 0.95), eps=1e-6)
+                lr=5e-4, betas=(0.9, 0.95), eps=1e-6,
+                clamp=(model.logit_scale, 0.0, math.log(100)))      # train.py:285-286, fused into the update kernel
     step_model = model
     if dist_on:
         step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], static_graph=True)
     loss_fn = clipa_amd.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True, rank=rank, world_size=world)
 
     B = args.batch
-    img_cpu, txt_cpu = O.synthetic_batch(min(B, 256), args.image_size, args.ctx, cfg["text_cfg"]["vocab_size"],
-                                         seed=1234 + rank)
-    reps = (B + img_cpu.shape[0] - 1) // img_cpu.shape[0]
-    images = img_cpu.to(dev).repeat(reps, 1, 1, 1)[:B].contiguous()
-    # de-duplicate the tiled synthetic images so no two pairs of the batch are identical
-    images += (torch.arange(B, device=dev, dtype=torch.int64) % 251).to(torch.uint8).view(B, 1, 1, 1)
-    texts = txt_cpu.to(dev).repeat(reps, 1)[:B].contiguous()
-    texts[:, 1] = 1 + (torch.arange(B, device=dev) % 40000)
+    from clipa_amd.data import synthetic_batch
+    # uint8 NHWC (channels_last) images + int64 token ids, resident in HBM before the timed region
+    images, texts = synthetic_batch(B, args.image_size, args.ctx, cfg["text_cfg"]["vocab_size"], seed=1234 + rank, device=dev)
 
     def step():
         opt.zero_grad(set_to_none=True)
         out = step_model(images, texts)
         loss = loss_fn(**out, output_dict=True)["contrastive_loss"]
         loss.backward()
-        opt.step()
-        with torch.no_grad():
-            model.logit_scale.clamp_(0, math.log(100))        # train.py:285-286
+        opt.step()                                             # AdamW + logit_scale clamp, multi-tensor kernels
         return loss
 
     def fence():
@@ -198,9 +201,12 @@ def main():
         total_mem = torch.cuda.get_device_properties(dev).total_memory
         torch.cuda.reset_peak_memory_stats(dev)
         step()                                   # one extra untimed all-recompute step, only to measure its peak
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()                 # (under DDP this peak already contains the reducer's buckets)
         peak = torch.cuda.max_memory_allocated(dev)
-        budget0 = int(args.keep_fraction * (total_mem - peak)) - (6 << 30)
+        frac = args.keep_fraction if args.keep_fraction is not None else (0.86 if dist_on else 0.93)
+        budget0 = int(frac * (total_mem - peak)) - (6 << 30)
+        if dist_on:
+            budget0 = agree_budget(budget0, dev)
         # Spend the budget where a byte saves the most recompute FLOPs: "medium" tier first (drops LN1, in-proj,
         # attention, out-proj: ~17.5 of a block's 25.5 D^2 units for 5 D bytes per token), image tower before
         # text (wider), then upgrades medium -> "light" (the remaining 8 units for 4 more D bytes).
@@ -211,9 +217,10 @@ def main():
             return plan_keep(budget, cfg["vision_cfg"]["layers"], cfg["text_cfg"]["layers"], mv_b, mt_b, lv_b, lt_b)
 
         keep_v, keep_t, med_v, med_t = plan(budget0)
-        if world == 1:
-            # trial step under the plan; an allocator-fragmentation OOM shrinks the budget instead of failing the run
-            # (single process only: with several ranks one rank backing off alone would desynchronise the collectives)
+        if not dist_on:
+            # trial step under the plan; an allocator-fragmentation OOM shrinks the budget instead of failing the run.
+            # Single process only: a rank that backs off alone would leave its peers inside a DDP all-reduce - with
+            # several ranks the smaller keep fraction above is the safety margin instead.
             for attempt in range(4):
                 set_keep(keep_v, keep_t, med_v, med_t)
                 try:
@@ -275,7 +282,7 @@ def main():
             "loss": round(last_loss, 4), "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
             "peak_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2**30, 1),
             "alloc_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)),
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt2_kernel (bf16 v_mfma_f32_16x16x32, 256x256x64 tile)", "achieved": round(achieved, 1),
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt (gemm_nt2 / gemm_ntd: bf16 v_mfma_f32_16x16x32, 256x256x64 tile)", "achieved": round(achieved, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                          "traffic": traffic, "algorithmic_bytes_per_launch": round(nt.get("bytes", 0.0) / max(nt["launches"], 1)),
                          "launches": nt["launches"],

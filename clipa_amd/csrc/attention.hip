@@ -16,6 +16,7 @@
 // ds_read_b64_tr_b16.  The backward pass is two sweeps (query-major for dQ, key-major for dK/dV)
 // that recompute the probabilities from per-row (max, 1/sum) statistics kept in LDS.
 #include "common.h"
+#include <mutex>
 #include "clipa_hip.h"
 
 namespace {
@@ -420,16 +421,24 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
   }
 }
 
+constexpr int ATTN_MAX_DEVICES = 64;
+
 template <int NKT, int DH, bool CAUSAL>
 int launch_fwd_c(const AttnArgs& a, hipStream_t st) {
   constexpr int HPW = WGHeads<NKT>::HPW;
   const int lds = HPW * 2 * NKT * 32 * HD<DH>::RB;
-  static bool done = false;
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NKT, DH, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) { clipa_set_error("attn_fwd attr: %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
-    done = true;
-  }
+  // the LDS opt-in is a per-device function attribute: once per (kernel instantiation, device), thread-safe (the
+  // forward runs on the Python main thread, the backward on autograd's worker thread)
+  static std::once_flag once[ATTN_MAX_DEVICES];
+  static int rc_dev[ATTN_MAX_DEVICES];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ATTN_MAX_DEVICES) { clipa_set_error("attn_fwd: bad device"); return CLIPA_ERR_LAUNCH; }
+  std::call_once(once[dev], [&]() {
+    const hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NKT, DH, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    rc_dev[dev] = 0;
+    if (e != hipSuccess) { clipa_set_error("attn_fwd attr: %s", hipGetErrorString(e)); rc_dev[dev] = CLIPA_ERR_LAUNCH; }
+  });
+  if (rc_dev[dev]) return rc_dev[dev];
   hipLaunchKernelGGL((attn_fwd_kernel<NKT, DH, CAUSAL>), dim3((unsigned)(((long)a.B * a.H + HPW - 1) / HPW)), dim3(256), lds, st, a);
   return clipa_check_launch("attn_fwd");
 }
@@ -441,12 +450,18 @@ template <int NKT, int DH, bool CAUSAL>
 int launch_bwd_c(const AttnArgs& a, hipStream_t st) {
   constexpr int HPW = WGHeads<NKT>::HPW;
   const int lds = HPW * (2 * NKT * 32 * HD<DH>::RB + 3 * NKT * 32 * 4);
-  static bool done = false;
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NKT, DH, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) { clipa_set_error("attn_bwd attr: %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
-    done = true;
-  }
+  // the LDS opt-in is a per-device function attribute: once per (kernel instantiation, device), thread-safe (the
+  // forward runs on the Python main thread, the backward on autograd's worker thread)
+  static std::once_flag once[ATTN_MAX_DEVICES];
+  static int rc_dev[ATTN_MAX_DEVICES];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ATTN_MAX_DEVICES) { clipa_set_error("attn_bwd: bad device"); return CLIPA_ERR_LAUNCH; }
+  std::call_once(once[dev], [&]() {
+    const hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NKT, DH, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    rc_dev[dev] = 0;
+    if (e != hipSuccess) { clipa_set_error("attn_bwd attr: %s", hipGetErrorString(e)); rc_dev[dev] = CLIPA_ERR_LAUNCH; }
+  });
+  if (rc_dev[dev]) return rc_dev[dev];
   hipLaunchKernelGGL((attn_bwd_kernel<NKT, DH, CAUSAL>), dim3((unsigned)(((long)a.B * a.H + HPW - 1) / HPW)), dim3(256), lds, st, a);
   return clipa_check_launch("attn_bwd");
 }

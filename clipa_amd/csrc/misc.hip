@@ -112,7 +112,7 @@ __global__ void assemble_tokens_bwd_kernel(const unsigned short* __restrict__ dt
 template <bool TBF16>
 __global__ void embed_tokens_kernel(const long* __restrict__ ids, const void* __restrict__ table,
                                     const float* __restrict__ pos, unsigned short* __restrict__ out,
-                                    long B, int T, int D, int vocab) {
+                                    long B, int T, int D, int vocab, int* __restrict__ oob) {
   const int dc = D / 8;
   const long total = B * T * dc;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -120,8 +120,10 @@ __global__ void embed_tokens_kernel(const long* __restrict__ ids, const void* __
     const long row = idx / dc;
     const int t = (int)(row % T);
     long id = ids[row];
-    if (id < 0) id = 0;
-    if (id >= vocab) id = vocab - 1;
+    if (id < 0 || id >= vocab) {          // nn.Embedding raises here; report through the caller's counter
+      if (c == 0 && oob) atomicAdd(oob, 1);
+      id = 0;
+    }
     float v[8], pe[8];
     if (TBF16) {
       unpack8(*(const u32x4*)((const unsigned short*)table + (size_t)id * D + c * 8), v);
@@ -142,7 +144,7 @@ __global__ void embed_tokens_kernel(const long* __restrict__ ids, const void* __
 // dtable[ids[b,t],:] += dx[b,t,:] (fp32 atomics; all-zero rows - every position after EOT under the
 // causal mask - are skipped); dpos via assemble_tokens_bwd-style reduction is done by a second call.
 __global__ void embed_tokens_bwd_kernel(const long* __restrict__ ids, const unsigned short* __restrict__ dx,
-                                        float* __restrict__ dtable, long B, int T, int D, int vocab) {
+                                        float* __restrict__ dtable, long B, int T, int D, int vocab, int* __restrict__ oob) {
   const int dc = D / 8;
   const long total = B * T * dc;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -150,9 +152,11 @@ __global__ void embed_tokens_bwd_kernel(const long* __restrict__ ids, const unsi
     const long row = idx / dc;
     const u32x4 raw = *(const u32x4*)(dx + (size_t)row * D + c * 8);
     if (((raw[0] | raw[1] | raw[2] | raw[3]) & 0x7fff7fffu) == 0) continue;
-    long id = ids[row];
-    if (id < 0) id = 0;
-    if (id >= vocab) id = vocab - 1;
+    const long id = ids[row];
+    if (id < 0 || id >= vocab) {          // never scatter outside the table: count and skip
+      if (c == 0 && oob) atomicAdd(oob, 1);
+      continue;
+    }
     float v[8];
     unpack8(raw, v);
 #pragma unroll
@@ -497,23 +501,24 @@ extern "C" int clipa_assemble_tokens_bwd(const void* dtokens, void* dpatch, floa
 }
 
 extern "C" int clipa_embed_tokens(const int64_t* ids, const void* table, int table_bf16, const float* pos,
-                                  void* out, int64_t B, int64_t T, int64_t D, int64_t vocab, void* stream) {
+                                  void* out, int64_t B, int64_t T, int64_t D, int64_t vocab, int32_t* oob_count,
+                                  void* stream) {
   if (D % 8 != 0) { clipa_set_error("embed_tokens: D%%8 != 0"); return CLIPA_ERR_ARG; }
   if (B <= 0) return CLIPA_OK;
   const unsigned grid = grid_for(B * T * (D / 8));
-  if (table_bf16) hipLaunchKernelGGL(embed_tokens_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const long*)ids, table, pos, (unsigned short*)out, (long)B, (int)T, (int)D, (int)vocab);
-  else hipLaunchKernelGGL(embed_tokens_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const long*)ids, table, pos, (unsigned short*)out, (long)B, (int)T, (int)D, (int)vocab);
+  if (table_bf16) hipLaunchKernelGGL(embed_tokens_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const long*)ids, table, pos, (unsigned short*)out, (long)B, (int)T, (int)D, (int)vocab, oob_count);
+  else hipLaunchKernelGGL(embed_tokens_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const long*)ids, table, pos, (unsigned short*)out, (long)B, (int)T, (int)D, (int)vocab, oob_count);
   return clipa_check_launch("embed_tokens");
 }
 
 extern "C" int clipa_embed_tokens_bwd(const int64_t* ids, const void* dx, float* dtable, float* dpos,
-                                      int64_t B, int64_t T, int64_t D, int64_t vocab, void* stream) {
+                                      int64_t B, int64_t T, int64_t D, int64_t vocab, int32_t* oob_count, void* stream) {
   if (D % 8 != 0) { clipa_set_error("embed_tokens_bwd: D%%8 != 0"); return CLIPA_ERR_ARG; }
   if (B <= 0) return CLIPA_OK;
   hipStream_t st = (hipStream_t)stream;
   if (dtable) {
     (void)hipMemsetAsync(dtable, 0, vocab * D * sizeof(float), st);
-    hipLaunchKernelGGL(embed_tokens_bwd_kernel, dim3(grid_for(B * T * (D / 8))), dim3(256), 0, st, (const long*)ids, (const unsigned short*)dx, dtable, (long)B, (int)T, (int)D, (int)vocab);
+    hipLaunchKernelGGL(embed_tokens_bwd_kernel, dim3(grid_for(B * T * (D / 8))), dim3(256), 0, st, (const long*)ids, (const unsigned short*)dx, dtable, (long)B, (int)T, (int)D, (int)vocab, oob_count);
     if (int rc = clipa_check_launch("embed_tokens_bwd")) return rc;
   }
   if (dpos) return clipa_assemble_tokens_bwd(dx, nullptr, nullptr, dpos, B, T, D, stream);

@@ -58,6 +58,9 @@ struct MTArgs {
   int blk0[MT_MAX + 1];
   int count;
   float lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale;
+  const float* gscale_dev;     // optional: gradients are additionally scaled by gscale_dev[0] (the clip coefficient)
+  int clamp_slot;              // >= 0: the updated values of that tensor are clamped to [clamp_lo, clamp_hi]
+  float clamp_lo, clamp_hi;
 };
 template <bool PF32, bool GF32>
 __global__ void adamw_multi_kernel(MTArgs a) {
@@ -69,9 +72,11 @@ __global__ void adamw_multi_kernel(MTArgs a) {
   const void* grad = a.g[t];
   float* m = a.m[t];
   float* v = a.v[t];
+  const float gscale = a.gscale_dev ? a.gscale * a.gscale_dev[0] : a.gscale;
+  const bool clamp = t == a.clamp_slot;
   for (long i = base + threadIdx.x; i < n && i < base + MT_CHUNK; i += blockDim.x) {
     float p = PF32 ? ((float*)param)[i] : bf2f(((unsigned short*)param)[i]);
-    const float g = (GF32 ? ((const float*)grad)[i] : bf2f(((const unsigned short*)grad)[i])) * a.gscale;
+    const float g = (GF32 ? ((const float*)grad)[i] : bf2f(((const unsigned short*)grad)[i])) * gscale;
     p *= 1.0f - a.lr * a.wd;
     const float mi = a.b1 * m[i] + (1.0f - a.b1) * g;
     const float vi = a.b2 * v[i] + (1.0f - a.b2) * g * g;
@@ -79,30 +84,95 @@ __global__ void adamw_multi_kernel(MTArgs a) {
     v[i] = vi;
     const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
     p -= (a.lr / a.bc1) * (mi / denom);
+    if (clamp) p = fminf(fmaxf(p, a.clamp_lo), a.clamp_hi);
     if (PF32) ((float*)param)[i] = p;
     else ((unsigned short*)param)[i] = f2bf(p);
   }
 }
+
+// sum of squares of many gradient tensors (clip_grad_norm_'s total norm, train.py:270-277): block partial -> one atomic
+template <bool GF32>
+__global__ void sqnorm_multi_kernel(MTArgs a, float* __restrict__ acc) {
+  __shared__ float red[4];
+  int t = 0;
+  while (t + 1 < a.count && (int)blockIdx.x >= a.blk0[t + 1]) ++t;
+  const long base = (long)((int)blockIdx.x - a.blk0[t]) * MT_CHUNK;
+  const long n = a.n[t];
+  const void* grad = a.g[t];
+  float s = 0.f;
+  for (long i = base + threadIdx.x; i < n && i < base + MT_CHUNK; i += blockDim.x) {
+    const float g = GF32 ? ((const float*)grad)[i] : bf2f(((const unsigned short*)grad)[i]);
+    s += g * g;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
+}
+__global__ void clip_coef_kernel(const float* __restrict__ acc, float max_norm, float* __restrict__ norm_out, float* __restrict__ coef_out) {
+  const float n = sqrtf(acc[0]);
+  if (norm_out) norm_out[0] = n;
+  const float c = max_norm / (n + 1e-6f);      // torch.nn.utils.clip_grad_norm_: clip_coef clamped to <= 1
+  coef_out[0] = c < 1.0f ? c : 1.0f;
+}
 }  // namespace
+
+extern "C" int clipa_grad_sqnorm_multi(const void* const* grads, const int64_t* numel, int count, int grad_f32, float* acc,
+                                       void* stream) {
+  if (count <= 0) return CLIPA_OK;
+  if (!grads || !numel || !acc) { clipa_set_error("grad_sqnorm_multi: null argument"); return CLIPA_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  for (int next = 0; next < count;) {
+    MTArgs a;
+    a.count = 0;
+    a.blk0[0] = 0;
+    int i = next;
+    for (; i < count && a.count < MT_MAX; ++i) {
+      if (numel[i] <= 0) continue;
+      const int c = a.count++;
+      a.g[c] = grads[i]; a.n[c] = (long)numel[i];
+      a.blk0[c + 1] = a.blk0[c] + (int)((numel[i] + MT_CHUNK - 1) / MT_CHUNK);
+    }
+    next = i;
+    if (a.count == 0) continue;
+    const unsigned grid = (unsigned)a.blk0[a.count];
+    if (grad_f32) hipLaunchKernelGGL(sqnorm_multi_kernel<true>, dim3(grid), dim3(256), 0, st, a, acc);
+    else hipLaunchKernelGGL(sqnorm_multi_kernel<false>, dim3(grid), dim3(256), 0, st, a, acc);
+    if (int rc = clipa_check_launch("grad_sqnorm_multi")) return rc;
+  }
+  return CLIPA_OK;
+}
+
+extern "C" int clipa_clip_coef(const float* acc, float max_norm, float* norm_out, float* coef_out, void* stream) {
+  if (!acc || !coef_out) { clipa_set_error("clip_coef: null argument"); return CLIPA_ERR_ARG; }
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, acc, max_norm, norm_out, coef_out);
+  return clipa_check_launch("clip_coef");
+}
 
 extern "C" int clipa_adamw_multi(void* const* params, const void* const* grads, float* const* exp_avg,
                                  float* const* exp_avg_sq, const int64_t* numel, int count, int param_f32,
                                  int grad_f32, float lr, float beta1, float beta2, float eps, float weight_decay,
-                                 int64_t step, float grad_scale, void* stream) {
+                                 int64_t step, float grad_scale, const float* grad_scale_dev, int clamp_index,
+                                 float clamp_lo, float clamp_hi, void* stream) {
   if (count <= 0) return CLIPA_OK;
   if (step < 1) { clipa_set_error("adamw_multi: step must be >= 1"); return CLIPA_ERR_ARG; }
   if (!params || !grads || !exp_avg || !exp_avg_sq || !numel) { clipa_set_error("adamw_multi: null table"); return CLIPA_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
-  for (int first = 0; first < count; first += MT_MAX) {
+  for (int next = 0; next < count;) {
     MTArgs a;
     a.count = 0;
     a.blk0[0] = 0;
-    for (int i = first; i < count && a.count < MT_MAX; ++i) {
+    a.clamp_slot = -1;
+    a.clamp_lo = clamp_lo; a.clamp_hi = clamp_hi; a.gscale_dev = grad_scale_dev;
+    int i = next;                      // consumed index: empty tensors are skipped without using up a slot
+    for (; i < count && a.count < MT_MAX; ++i) {
       if (numel[i] <= 0) continue;
       const int c = a.count++;
+      if (i == clamp_index) a.clamp_slot = c;
       a.p[c] = params[i]; a.g[c] = grads[i]; a.m[c] = exp_avg[i]; a.v[c] = exp_avg_sq[i]; a.n[c] = (long)numel[i];
       a.blk0[c + 1] = a.blk0[c] + (int)((numel[i] + MT_CHUNK - 1) / MT_CHUNK);
     }
+    next = i;
     if (a.count == 0) continue;
     a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = weight_decay; a.gscale = grad_scale;
     a.bc1 = 1.0f - powf(beta1, (float)step);

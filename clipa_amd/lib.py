@@ -30,8 +30,8 @@ SIGNATURES = {
     "clipa_patchify": (_I32, [_P, _P, _I64, _I64, _I64, _I64, _I32, _I32, _I32, _c.POINTER(_F), _c.POINTER(_F), _P]),
     "clipa_assemble_tokens": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
     "clipa_assemble_tokens_bwd": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
-    "clipa_embed_tokens": (_I32, [_P, _P, _I32, _P, _P, _I64, _I64, _I64, _I64, _P]),
-    "clipa_embed_tokens_bwd": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
+    "clipa_embed_tokens": (_I32, [_P, _P, _I32, _P, _P, _I64, _I64, _I64, _I64, _P, _P]),
+    "clipa_embed_tokens_bwd": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P]),
     "clipa_argmax_tokens": (_I32, [_P, _P, _I64, _I64, _P]),
     "clipa_pool_fwd": (_I32, [_P, _P, _P, _I64, _I64, _I64, _I32, _P]),
     "clipa_pool_bwd": (_I32, [_P, _P, _P, _I64, _I64, _I64, _I32, _P]),
@@ -46,7 +46,9 @@ SIGNATURES = {
     "clipa_ce_rows": (_I32, [_P, _I64, _I64, _I64, _I64, _F, _P, _P, _I64, _P, _P, _P]),
     "clipa_sum_scale": (_I32, [_P, _P, _I64, _F, _I32, _P]),
     "clipa_adamw": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _F, _F, _F, _F, _F, _I64, _F, _P]),
-    "clipa_adamw_multi": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _F, _F, _F, _F, _F, _I64, _F, _P]),
+    "clipa_adamw_multi": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _F, _F, _F, _F, _F, _I64, _F, _P, _I32, _F, _F, _P]),
+    "clipa_grad_sqnorm_multi": (_I32, [_P, _P, _I32, _I32, _P, _P]),
+    "clipa_clip_coef": (_I32, [_P, _F, _P, _P, _P]),
 }
 
 _lib = None

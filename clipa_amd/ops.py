@@ -251,15 +251,51 @@ def assemble_tokens_bwd(dtok, B, L, need_pos=True):
     return dpatch, dcls, dpos
 
 
+# Out-of-range token ids: nn.Embedding raises; the kernels count them into a device int32 instead of clamping silently.
+# The count is fetched without stalling the stream (pinned buffer + event) and checked at the next embedding call or by
+# `check_token_ids()`: a bad id surfaces as a RuntimeError at most one step late.
+_OOB_PENDING = []
+
+
+def _oob_counter(device):
+    return torch.zeros(1, device=device, dtype=torch.int32)
+
+
+def _oob_submit(counter, what):
+    host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+    host.copy_(counter, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _OOB_PENDING.append((host, ev, what, counter))
+
+
+def check_token_ids(wait=False):
+    """Raise if an earlier embedding forward / backward met token ids outside the table (wait=True: block on all)."""
+    keep = []
+    for host, ev, what, counter in _OOB_PENDING:
+        if wait:
+            ev.synchronize()
+        if ev.query():
+            if int(host[0]) != 0:
+                _OOB_PENDING.clear()
+                raise RuntimeError(f"clipa_amd.ops.{what}: {int(host[0])} token ids outside [0, vocab) (nn.Embedding would raise)")
+        else:
+            keep.append((host, ev, what, counter))
+    _OOB_PENDING[:] = keep
+
+
 def embed_tokens(ids, table, pos):
     _chk(ids, torch.int64, "ids", 2)
     _chk(pos, f32, "pos", 2)
+    check_token_ids()
     ids = ids.contiguous()
     B, T = ids.shape
     V, D = table.shape
     out = torch.empty((B * T, D), device=ids.device, dtype=bf16)
+    oob = _oob_counter(ids.device)
     lib.call("clipa_embed_tokens", _p(ids), _p(table.contiguous()), int(table.dtype == bf16), _p(pos.contiguous()), _p(out),
-             B, T, D, V, _stream())
+             B, T, D, V, _p(oob), _stream())
+    _oob_submit(oob, "embed_tokens")
     return out
 
 
@@ -270,7 +306,9 @@ def embed_tokens_bwd(ids, dx, vocab, need_table=True, need_pos=True):
     dx = dx.contiguous()
     dtable = torch.empty((vocab, D), device=dx.device, dtype=f32) if need_table else None
     dpos = torch.empty((T, D), device=dx.device, dtype=f32) if need_pos else None
-    lib.call("clipa_embed_tokens_bwd", _p(ids), _p(dx), _p(dtable), _p(dpos), B, T, D, vocab, _stream())
+    oob = _oob_counter(ids.device)
+    lib.call("clipa_embed_tokens_bwd", _p(ids), _p(dx), _p(dtable), _p(dpos), B, T, D, vocab, _p(oob), _stream())
+    _oob_submit(oob, "embed_tokens_bwd")
     return dtable, dpos
 
 
@@ -388,24 +426,61 @@ def sum_scale(x, scale, out=None, accumulate=False):
     return out
 
 
+def _chk_moments(p, m, v):
+    for name, t in (("exp_avg", m), ("exp_avg_sq", v)):
+        if t.dtype != f32 or not t.is_contiguous() or t.numel() != p.numel() or not t.is_cuda:
+            raise RuntimeError(f"adamw: {name} must be a contiguous f32 GPU tensor with the parameter's numel (got {t.dtype}, "
+                               f"{t.numel()} vs {p.numel()}) - the kernel reads and writes it as float*")
+
+
 def adamw_(param, grad, exp_avg, exp_avg_sq, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    _chk_moments(param, exp_avg, exp_avg_sq)
     lib.call("clipa_adamw", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), int(param.dtype == f32),
              int(grad.dtype == f32), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
              float(grad_scale), _stream())
 
 
-def adamw_multi_(params, grads, exp_avgs, exp_avg_sqs, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
-    """One AdamW update over a list of tensors that share dtypes, hyper-parameters and step count."""
+def adamw_multi_(params, grads, exp_avgs, exp_avg_sqs, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0,
+                 grad_scale_dev=None, clamp_index=-1, clamp=(0.0, 0.0)):
+    """One AdamW update over a list of tensors that share dtypes, hyper-parameters and step count.  grad_scale_dev: f32
+    device scalar multiplied into every gradient (clip coefficient); clamp_index: list position of the tensor that is
+    clamped to `clamp` after its update."""
     n = len(params)
     if n == 0:
         return
     pf32, gf32 = params[0].dtype == f32, grads[0].dtype == f32
-    for t, g in zip(params, grads):
+    for t, g, m, v in zip(params, grads, exp_avgs, exp_avg_sqs):
         if (t.dtype == f32) != pf32 or (g.dtype == f32) != gf32 or not t.is_cuda:
             raise RuntimeError("adamw_multi_: mixed dtypes in one call / tensors must live on the GPU")
+        if t.dtype not in (f32, bf16) or g.dtype not in (f32, bf16) or g.numel() != t.numel() or not t.is_contiguous() \
+                or not g.is_contiguous():
+            raise RuntimeError("adamw_multi_: parameters / gradients must be contiguous f32 or bf16 tensors of equal numel")
+        _chk_moments(t, m, v)
+    if grad_scale_dev is not None:
+        _chk(grad_scale_dev, f32, "grad_scale_dev")
     arr = ctypes.c_void_p * n
     cnt = (ctypes.c_int64 * n)(*[t.numel() for t in params])
     lib.call("clipa_adamw_multi", arr(*[t.data_ptr() for t in params]), arr(*[t.data_ptr() for t in grads]),
              arr(*[t.data_ptr() for t in exp_avgs]), arr(*[t.data_ptr() for t in exp_avg_sqs]), cnt, n, int(pf32),
              int(gf32), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
-             float(grad_scale), _stream())
+             float(grad_scale), _p(grad_scale_dev), int(clamp_index), float(clamp[0]), float(clamp[1]), _stream())
+
+
+def grad_clip_coef(grads, max_norm):
+    """clip_grad_norm_ on the device: -> (total_norm, coef) f32 device scalars, coef = min(1, max_norm / (norm + 1e-6))."""
+    dev = grads[0].device
+    buf = torch.zeros(3, device=dev, dtype=f32)           # [sum of squares, norm, coef]
+    for is32 in (True, False):
+        sel = [g for g in grads if (g.dtype == f32) == is32]
+        if not sel:
+            continue
+        for g in sel:
+            if g.dtype not in (f32, bf16) or not g.is_contiguous() or not g.is_cuda:
+                raise RuntimeError("grad_clip_coef: gradients must be contiguous f32 / bf16 GPU tensors")
+        n = len(sel)
+        arr = ctypes.c_void_p * n
+        cnt = (ctypes.c_int64 * n)(*[g.numel() for g in sel])
+        lib.call("clipa_grad_sqnorm_multi", arr(*[g.data_ptr() for g in sel]), cnt, n, int(is32), _p(buf), _stream())
+    lib.call("clipa_clip_coef", _p(buf), float(max_norm), ctypes.c_void_p(buf.data_ptr() + 4), ctypes.c_void_p(buf.data_ptr() + 8),
+             _stream())
+    return buf[1], buf[2]

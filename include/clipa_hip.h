@@ -94,9 +94,12 @@ int clipa_assemble_tokens_bwd(const void* dtokens, void* dpatch, float* dcls, fl
                               int64_t L, int64_t D, void* stream);
 /* token_embedding(text) + positional_embedding (model.py:245-247) and gradients (dense f32 table grad). */
 int clipa_embed_tokens(const int64_t* ids, const void* table, int table_bf16, const float* pos, void* out,
-                       int64_t B, int64_t T, int64_t D, int64_t vocab, void* stream);
+                       int64_t B, int64_t T, int64_t D, int64_t vocab, int32_t* oob_count, void* stream);
+/* oob_count (device int32, may be NULL): incremented once per token id outside [0, vocab) - nn.Embedding raises on
+ * those; the forward substitutes row 0, the backward skips the row, the caller turns a non-zero count into an error
+ * (clipa_amd.ops checks it asynchronously). */
 int clipa_embed_tokens_bwd(const int64_t* ids, const void* dx, float* dtable, float* dpos, int64_t B,
-                           int64_t T, int64_t D, int64_t vocab, void* stream);
+                           int64_t T, int64_t D, int64_t vocab, int32_t* oob_count, void* stream);
 /* text.argmax(dim=-1) (model.py:254) */
 int clipa_argmax_tokens(const int64_t* ids, int32_t* out, int64_t B, int64_t T, void* stream);
 /* pooling [B,L,D] bf16 -> [B,D] f32 and its gradient (writes all of dx) */
@@ -136,11 +139,21 @@ int clipa_adamw(void* param, const void* grad, float* exp_avg, float* exp_avg_sq
                 int grad_f32, float lr, float beta1, float beta2, float eps, float weight_decay,
                 int64_t step, float grad_scale, void* stream);
 /* The same update over `count` tensors that share dtypes, hyper-parameters and step (one parameter group of
- * main.py:311-326): HOST arrays of device pointers / element counts; a few launches instead of one per tensor. */
+ * main.py:311-326): HOST arrays of device pointers / element counts; a few launches instead of one per tensor.
+ * Fused optimizer tail (train.py:270-286): grad_scale_dev (optional DEVICE float, e.g. the clip coefficient of
+ * clipa_clip_coef) multiplies every gradient; tensor `clamp_index` (-1: none) is clamped to [clamp_lo, clamp_hi]
+ * after its update (logit_scale.clamp_(0, ln 100)). */
 int clipa_adamw_multi(void* const* params, const void* const* grads, float* const* exp_avg,
                       float* const* exp_avg_sq, const int64_t* numel, int count, int param_f32, int grad_f32,
                       float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
-                      float grad_scale, void* stream);
+                      float grad_scale, const float* grad_scale_dev, int clamp_index, float clamp_lo, float clamp_hi,
+                      void* stream);
+/* torch.nn.utils.clip_grad_norm_ (train.py:270-277) without a host round trip: acc[0] += sum of squares of the listed
+ * gradients (zero it first; call once per dtype bucket), then coef = min(1, max_norm / (sqrt(acc) + 1e-6)) and the
+ * norm itself land in device memory for clipa_adamw_multi's grad_scale_dev. */
+int clipa_grad_sqnorm_multi(const void* const* grads, const int64_t* numel, int count, int grad_f32, float* acc,
+                            void* stream);
+int clipa_clip_coef(const float* acc, float max_norm, float* norm_out, float* coef_out, void* stream);
 
 #ifdef __cplusplus
 }

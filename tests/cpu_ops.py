@@ -202,6 +202,15 @@ def adamw_(param, grad, exp_avg, exp_avg_sq, *, lr, beta1, beta2, eps, weight_de
     param.copy_((p - lr / (1 - beta1 ** step) * exp_avg / denom).to(param.dtype))
 
 
-def adamw_multi_(params, grads, exp_avgs, exp_avg_sqs, **kw):
-    for p, g, m, v in zip(params, grads, exp_avgs, exp_avg_sqs):
+def adamw_multi_(params, grads, exp_avgs, exp_avg_sqs, grad_scale_dev=None, clamp_index=-1, clamp=(0.0, 0.0), **kw):
+    if grad_scale_dev is not None:
+        kw = dict(kw, grad_scale=kw.get("grad_scale", 1.0) * float(grad_scale_dev))
+    for k, (p, g, m, v) in enumerate(zip(params, grads, exp_avgs, exp_avg_sqs)):
         adamw_(p, g, m, v, **kw)
+        if k == clamp_index:
+            p.clamp_(clamp[0], clamp[1])
+
+
+def grad_clip_coef(grads, max_norm):
+    norm = torch.sqrt(sum((g.float() ** 2).sum() for g in grads))
+    return norm, torch.clamp(max_norm / (norm + 1e-6), max=1.0)

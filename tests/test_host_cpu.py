@@ -172,3 +172,58 @@ def test_bench_keep_planner_respects_the_budget():
     kv, kt, dv, dt = bench.plan_keep(200 << 30, 24, 12, mv, mt, lv, lt)
     assert (kv, kt, dv) == (0, 0, 24) and 1 <= dt <= 12            # medium everywhere in the image tower before any upgrade
     assert bench.plan_keep(2000 << 30, 24, 12, mv, mt, lv, lt) == (24, 12, 0, 0)
+
+
+def test_optimizer_load_state_dict_restores_f32_moments():
+    """torch.optim.Optimizer.load_state_dict casts floating-point state to the parameter's dtype; the HIP kernel reads
+    the moments as float*, so clipa_amd.optim.AdamW must restore f32 (and an int step) after a resume - also from a
+    torch.optim.AdamW checkpoint with tensor steps."""
+    from clipa_amd.optim import AdamW
+    p = torch.nn.Parameter(torch.randn(16, 8).to(torch.bfloat16))
+    opt = AdamW([p], lr=1e-3)
+    opt.state[p] = {"step": 3, "exp_avg": torch.randn(16, 8), "exp_avg_sq": torch.rand(16, 8)}
+    sd = opt.state_dict()
+    opt2 = AdamW([p], lr=1e-3)
+    opt2.load_state_dict(sd)
+    st = opt2.state[p]
+    assert st["exp_avg"].dtype == torch.float32 and st["exp_avg_sq"].dtype == torch.float32 and st["step"] == 3
+    assert st["exp_avg"].is_contiguous()
+    t = torch.optim.AdamW([p], lr=1e-3)
+    p.grad = torch.zeros_like(p)
+    t.step()
+    opt3 = AdamW([p], lr=1e-3)
+    opt3.load_state_dict(t.state_dict())
+    st = opt3.state[p]
+    assert isinstance(st["step"], int) and st["step"] == 1 and st["exp_avg"].dtype == torch.float32
+
+
+def _budget_worker(rank, world, port, q):
+    import sys
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import bench
+    budget = bench.agree_budget((150 + 7 * rank) << 30, torch.device("cpu"))     # ranks measured different free HBM
+    mv, mt, lv, lt = 8_262_778_880, 2_422_210_560, 14_873_001_984, 4_359_979_008   # ViT-L/16, local batch 4096
+    q.put((rank, budget, bench.plan_keep(budget, 24, 12, mv, mt, lv, lt)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_keep_plan_is_rank_invariant():
+    """bench.py --keep-blocks auto under several ranks: the activation budget is MIN-reduced, so every rank derives the
+    same (light, medium) block counts although each measured a different peak (ranks could diverge)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_budget_worker, args=(r, 2, 29755, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][1] == got[1][1] == 150 << 30
+    assert got[0][2] == got[1][2]

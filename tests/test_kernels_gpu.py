@@ -407,3 +407,61 @@ def test_adamw_matches_torch(pdt, gdt):
         ops().adamw_(p, gstep.to(DEV), m, v, lr=1e-3, beta1=0.9, beta2=0.95, eps=1e-6,
                      weight_decay=0.2, step=step)
     check("adamw", p, ref.data, 2 ** -7 if pdt == bf16 else 1e-5, 1e-6)
+
+
+def test_embedding_reports_out_of_range_ids():
+    """nn.Embedding raises on ids outside the table; the kernels count them (no silent clamp) and clipa_amd.ops turns
+    the count into a RuntimeError."""
+    o = ops()
+    V, D, T = 64, 32, 8
+    table, tpos = rnd(V, D, seed=1, dtype=f32).to(DEV), rnd(T, D, seed=2, dtype=f32).to(DEV)
+    ids = torch.randint(0, V, (4, T))
+    o.embed_tokens(ids.to(DEV), table, tpos)
+    o.check_token_ids(wait=True)                      # clean batch: nothing to report
+    bad = ids.clone()
+    bad[1, 3] = V + 5
+    bad[2, 0] = -1
+    o.embed_tokens(bad.to(DEV), table, tpos)
+    with pytest.raises(RuntimeError, match="2 token ids outside"):
+        o.check_token_ids(wait=True)
+    dx = rnd(4 * T, D, seed=3).to(DEV)
+    dtable, _ = o.embed_tokens_bwd(bad.to(DEV), dx, V)
+    with pytest.raises(RuntimeError, match="token ids outside"):
+        o.check_token_ids(wait=True)
+    assert torch.isfinite(dtable).all()               # the bad rows were skipped, nothing was scattered out of bounds
+
+
+def test_optimizer_state_dict_round_trip_and_fused_tail():
+    """(1) state_dict() -> load_state_dict() with bf16 parameters: torch casts floating state to the parameter dtype;
+    the optimizer must hand the kernel f32 moments again (out-of-bounds writes otherwise).  (2) the fused
+    clip_grad_norm_ + logit-scale clamp tail equals the torch recipe of train.py:270-286."""
+    from clipa_amd.optim import AdamW
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(300, 40, device=DEV).to(bf16)), torch.nn.Parameter(torch.randn(77, device=DEV)),
+          torch.nn.Parameter(torch.tensor(4.0, device=DEV))]
+    ref = [torch.nn.Parameter(p.detach().float().clone()) for p in ps]
+    kw = dict(lr=1e-2, betas=(0.9, 0.95), eps=1e-6, weight_decay=0.1)
+    opt = AdamW(ps, grad_clip_norm=0.5, clamp=(ps[2], 0.0, 4.0), **kw)
+    ropt = torch.optim.AdamW(ref, **kw)
+    for step in range(4):
+        gs = [torch.randn_like(p.float()) * (3.0 if step % 2 else 0.01) for p in ps]
+        gs[2] = torch.tensor(-50.0, device=DEV)      # pushes the scalar up: the clamp at 4.0 must hold it
+        for p, r, g in zip(ps, ref, gs):
+            p.grad = g.to(p.dtype).clone()
+            r.grad = g.to(p.dtype).float().clone()      # separate storage: clip_grad_norm_ scales r.grad in place
+        torch.nn.utils.clip_grad_norm_(ref, 0.5)
+        ropt.step()
+        with torch.no_grad():
+            ref[2].clamp_(0.0, 4.0)
+        opt.step()
+        if step == 1:                                 # resume in the middle (training/main.py:338-356)
+            sd = opt.state_dict()
+            opt = AdamW(ps, grad_clip_norm=0.5, clamp=(ps[2], 0.0, 4.0), **kw)
+            opt.load_state_dict(sd)
+            for st in opt.state.values():
+                assert st["exp_avg"].dtype == f32 and st["exp_avg_sq"].dtype == f32 and isinstance(st["step"], int)
+    check("bf16 matrix", ps[0], ref[0].data, 2 ** -6, 2e-3)
+    check("f32 vector", ps[1], ref[1].data, 1e-4, 1e-5)
+    assert float(ps[2]) <= 4.0 and abs(float(ps[2]) - float(ref[2])) < 1e-4
+    want = torch.sqrt(sum((p.grad.float() ** 2).sum() for p in ps))
+    assert abs(float(opt.last_grad_norm) - float(want)) < 1e-3 * float(want)
