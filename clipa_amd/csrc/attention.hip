@@ -1,4 +1,5 @@
-// Fused multi-head self-attention forward / backward for short sequences (L <= 288, head dim 64 or 80)
+// Fused multi-head self-attention forward / backward for short sequences (L <= 288 in one piece, 288 < L <= 1024
+// streamed in 256-row chunks; head dim 64 or 80)
 // on gfx950.  Replaces torch scaled_dot_product_attention as called from nn.MultiheadAttention in
 // clipa_torch/open_clip/transformer.py:209,223-236 (softmax(q.k^T/sqrt(dh) + mask).v, dropout 0;
 // mask = None for the image tower, additive causal triu(1)*-inf for text, transformer.py:618-624).
@@ -421,6 +422,295 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LONG sequences (288 < L <= 1024: the 336-px stage of CLIPA-v2, 577 tokens at 14-px patches; ViT-L-16-320).  A whole
+// softmax row no longer fits in registers and the whole K / V (or Q / dO) of a head no longer fits in LDS, so keys
+// (forward, dQ sweep) or queries (dK / dV sweep) stream through LDS in chunks of CT 32-row tiles while the four
+// waves of the workgroup hold one 32-row tile each ("group"); the forward keeps a running (max, sum) per query row
+// and rescales its output accumulator per chunk (online softmax), the backward recomputes the probabilities from the
+// forward's final statistics exactly as the short kernels do.  Same fragments, swizzle and MFMA mapping as above.
+constexpr int LONG_CT = 8;          // 256 rows per chunk
+constexpr int LONG_LMAX = 1024;
+
+template <int DH>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t chunk_rsrc(const char* base, long ld, int row0, int L) {
+  const long rows = (long)L - row0;                       // rows of the head at / after row0
+  const long bytes = rows > 0 ? (rows - 1) * ld * 2 + DH * 2 : 0;
+  return make_rsrc(base + (size_t)row0 * ld * 2, (unsigned)bytes);
+}
+
+template <int DH, bool CAUSAL>
+__global__ __launch_bounds__(256, HD<DH>::WGS) void attn_fwd_long_kernel(AttnArgs p) {
+  constexpr int CT = LONG_CT, RB = HD<DH>::RB, KS = HD<DH>::KS, DT = HD<DH>::DT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* sK = smem;
+  char* sV = sK + CT * 32 * RB;
+  const int l31 = lane & 31, hi = lane >> 5, q16 = (lane >> 4) & 1, i16 = lane & 15;
+  const long head = blockIdx.x;
+  const int b = (int)(head / p.H), h = (int)(head - (long)b * p.H);
+  const char* qb = p.q + ((size_t)b * p.L * p.ld_qkv + (size_t)h * DH) * 2;
+  const char* kb = p.k + ((size_t)b * p.L * p.ld_qkv + (size_t)h * DH) * 2;
+  const char* vb = p.v + ((size_t)b * p.L * p.ld_qkv + (size_t)h * DH) * 2;
+  const __amdgpu_buffer_rsrc_t rsQ = chunk_rsrc<DH>(qb, p.ld_qkv, 0, p.L);
+  const int NT = (p.L + 31) / 32;
+  const float c = p.scale * 1.4426950408889634f;
+
+  for (int qt0 = 0; qt0 < NT; qt0 += 4) {
+    const int qt = qt0 + wave;
+    const int qg = 32 * qt + l31;                        // rows >= L read zeros and are never stored
+    bf16x8 fq[KS];
+    load_frags<KS>(rsQ, p.ld_qkv, qg, hi, fq);
+    const int lim2 = (CAUSAL ? min(p.L, qg + 1) : p.L) - 4 * hi;
+    float m_run = -1e30f, l_run = 0.f;
+    f32x16 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    for (int kc = 0; kc < NT; kc += CT) {
+      if (CAUSAL && kc > qt0 + 3) break;                 // every key of this chunk lies after every query of the group
+      const int nct = min(CT, NT - kc);
+      __syncthreads();                                   // the previous chunk has been consumed by every wave
+      dma_image<DH>(chunk_rsrc<DH>(kb, p.ld_qkv, 32 * kc, p.L), sK, nct * 32, p.ld_qkv, wave, lane, 4);
+      dma_image<DH>(chunk_rsrc<DH>(vb, p.ld_qkv, 32 * kc, p.L), sV, nct * 32, p.ld_qkv, wave, lane, 4);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      f32x16 s[CT];
+      float mx = -1e30f;
+#pragma unroll
+      for (int kt = 0; kt < CT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+        if (kt >= nct || (CAUSAL && kc + kt > qt)) continue;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct<DH>(sK, 32 * kt, l31, hi, ks), fq[ks], s[kt], 0, 0, 0);
+        const int T = kc + kt;
+        const bool full = (32 * T + 32 <= p.L) && (!CAUSAL || T < qt);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = s[kt][r];
+          if (!full) v = (32 * T + 8 * (r >> 2) + (r & 3) < lim2) ? v : -1e30f;
+          s[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);      // first chunk: exp2(-huge) = 0 on o = 0, l = 0
+      const float m2 = m_new * c;
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < CT; ++kt) {
+        if (kt >= nct || (CAUSAL && kc + kt > qt)) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = s[kt][r];
+          const float e = (v > -1e29f) ? __builtin_amdgcn_exp2f(fmaf(v, c, -m2)) : 0.f;   // masked entries contribute nothing
+          s[kt][r] = e;
+          sum += e;
+        }
+      }
+      sum += __shfl_xor(sum, 32, 64);
+      l_run = l_run * alpha + sum;
+      m_run = m_new;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+      for (int kt = 0; kt < CT; ++kt) {
+        if (kt >= nct || (CAUSAL && kc + kt > qt)) continue;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          float pv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pv[e] = s[kt][8 * s2 + e];
+          const bf16x8 pf = pack_frag(pv);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans<DH>(sV, 32 * kt + 16 * s2, 32 * dt, hi, q16, i16), pf, o[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (qg < p.L) {
+      const float inv = 1.0f / l_run;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+        store_frag_T(p.o, p.ld_o, (long)b * p.L + qg, h * DH + 32 * dt, hi, o[dt], inv, DH - 32 * dt);
+      if (p.stats && hi == 0) *(float2*)(p.stats + ((size_t)head * p.L + qg) * 2) = make_float2(m_run * c, inv);
+    }
+  }
+}
+
+template <int DH, bool CAUSAL>
+__global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_long_kernel(AttnArgs p) {
+  constexpr int CT = LONG_CT, RB = HD<DH>::RB, KS = HD<DH>::KS, DT = HD<DH>::DT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* img0 = smem;
+  char* img1 = img0 + CT * 32 * RB;
+  float* sM = (float*)(img0 + 2 * CT * 32 * RB);
+  float* sL = sM + LONG_LMAX;
+  float* sD = sL + LONG_LMAX;
+  const int l31 = lane & 31, hi = lane >> 5, q16 = (lane >> 4) & 1, i16 = lane & 15;
+  const long head = blockIdx.x;
+  const int b = (int)(head / p.H), h = (int)(head - (long)b * p.H);
+  const size_t hoff = ((size_t)b * p.L * p.ld_qkv + (size_t)h * DH) * 2;
+  const size_t ooff = ((size_t)b * p.L * p.ld_o + (size_t)h * DH) * 2;
+  const __amdgpu_buffer_rsrc_t rsQ = chunk_rsrc<DH>(p.q + hoff, p.ld_qkv, 0, p.L), rsK = chunk_rsrc<DH>(p.k + hoff, p.ld_qkv, 0, p.L),
+                               rsV = chunk_rsrc<DH>(p.v + hoff, p.ld_qkv, 0, p.L), rsDO = chunk_rsrc<DH>(p.d_o + ooff, p.ld_o, 0, p.L),
+                               rsO = chunk_rsrc<DH>(p.o_in + ooff, p.ld_o, 0, p.L);
+  const float c = p.scale * 1.4426950408889634f;
+  const float* stats = p.stats + (size_t)head * p.L * 2;
+  const int NT = (p.L + 31) / 32;
+
+  // ---- sweep 1: dQ (query groups outside, key chunks inside) ----------------------------------------------
+  for (int qt0 = 0; qt0 < NT; qt0 += 4) {
+    const int qt = qt0 + wave;
+    const int qg = 32 * qt + l31;
+    bf16x8 fq[KS], fdo[KS], fo[KS];
+    load_frags<KS>(rsQ, p.ld_qkv, qg, hi, fq);
+    load_frags<KS>(rsDO, p.ld_o, qg, hi, fdo);
+    load_frags<KS>(rsO, p.ld_o, qg, hi, fo);
+    float2 st = make_float2(0.f, 0.f);                 // padded queries: inv = 0 -> P = 0
+    if (qg < p.L) st = *(const float2*)(stats + qg * 2);
+    float Dq = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float a[8], o8[8];
+      unpack8(__builtin_bit_cast(u32x4, fdo[ks]), a);
+      unpack8(__builtin_bit_cast(u32x4, fo[ks]), o8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) Dq += a[i] * o8[i];
+    }
+    Dq += __shfl_xor(Dq, 32, 64);
+    if (hi == 0 && qt < NT) { sM[qg] = st.x; sL[qg] = st.y; sD[qg] = Dq; }
+    const int lim2 = (CAUSAL ? min(p.L, qg + 1) : p.L) - 4 * hi;
+    f32x16 dq[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+    for (int kc = 0; kc < NT; kc += CT) {
+      if (CAUSAL && kc > qt0 + 3) break;
+      const int nct = min(CT, NT - kc);
+      __syncthreads();
+      dma_image<DH>(chunk_rsrc<DH>(p.k + hoff, p.ld_qkv, 32 * kc, p.L), img0, nct * 32, p.ld_qkv, wave, lane, 4);
+      dma_image<DH>(chunk_rsrc<DH>(p.v + hoff, p.ld_qkv, 32 * kc, p.L), img1, nct * 32, p.ld_qkv, wave, lane, 4);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      for (int kt = 0; kt < nct; ++kt) {
+        const int T = kc + kt;
+        if (CAUSAL && T > qt) break;
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct<DH>(img0, 32 * kt, l31, hi, ks), fq[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct<DH>(img1, 32 * kt, l31, hi, ks), fdo[ks], dp, 0, 0, 0);
+        }
+        const bool full = (32 * T + 32 <= p.L) && (!CAUSAL || T < qt);
+        float ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float pe = __builtin_amdgcn_exp2f(fmaf(s[r], c, -st.x)) * st.y;
+          if (!full) pe = (32 * T + 8 * (r >> 2) + (r & 3) < lim2) ? pe : 0.f;
+          ds[r] = pe * (dp[r] - Dq) * p.scale;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 dsf = pack_frag(ds + 8 * s2);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+            dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans<DH>(img0, 32 * kt + 16 * s2, 32 * dt, hi, q16, i16), dsf, dq[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (qg < p.L) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+        store_frag_T(p.dq, p.ld_dqkv, (long)b * p.L + qg, h * DH + 32 * dt, hi, dq[dt], 1.0f, DH - 32 * dt);
+    }
+  }
+
+  // ---- sweep 2: dK, dV (key groups outside, query chunks inside) -----------------------------------------
+  for (int kt0 = 0; kt0 < NT; kt0 += 4) {
+    const int kt = kt0 + wave;
+    const int kg = 32 * kt + l31;
+    const int kgc = l31 - 4 * hi;      // causal test inside the diagonal tile: key <= query
+    bf16x8 fk[KS], fv[KS];
+    load_frags<KS>(rsK, p.ld_qkv, kg, hi, fk);
+    load_frags<KS>(rsV, p.ld_qkv, kg, hi, fv);
+    f32x16 dk[DT], dv[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+    for (int qc = 0; qc < NT; qc += CT) {
+      const int nct = min(CT, NT - qc);
+      if (CAUSAL && qc + nct <= kt0) continue;          // every query of the chunk lies before every key of the group
+      __syncthreads();                                  // (first pass: also orders sweep 1's statistics before their readers)
+      dma_image<DH>(chunk_rsrc<DH>(p.q + hoff, p.ld_qkv, 32 * qc, p.L), img0, nct * 32, p.ld_qkv, wave, lane, 4);
+      dma_image<DH>(chunk_rsrc<DH>(p.d_o + ooff, p.ld_o, 32 * qc, p.L), img1, nct * 32, p.ld_o, wave, lane, 4);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      for (int qi = 0; qi < nct; ++qi) {
+        const int T = qc + qi;                          // global query tile
+        if (CAUSAL && T < kt) continue;
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct<DH>(img0, 32 * qi, l31, hi, ks), fk[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct<DH>(img1, 32 * qi, l31, hi, ks), fv[ks], dp, 0, 0, 0);
+        }
+        float pr[16], ds[16];
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int q0 = 32 * T + 8 * rq + 4 * hi;
+          const float4 m4 = *(const float4*)(sM + q0);
+          const float4 l4 = *(const float4*)(sL + q0);
+          const float4 d4 = *(const float4*)(sD + q0);
+          const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
+          const float ll[4] = {l4.x, l4.y, l4.z, l4.w};
+          const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * rq + e;
+            float pe = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mm[e])) * ll[e];
+            if (CAUSAL && T == kt) pe = (kgc <= 8 * rq + e) ? pe : 0.f;
+            pr[r] = pe;
+            ds[r] = pe * (dp[r] - dd[e]) * p.scale;
+          }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pf = pack_frag(pr + 8 * s2);
+          const bf16x8 dsf = pack_frag(ds + 8 * s2);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans<DH>(img1, 32 * qi + 16 * s2, 32 * dt, hi, q16, i16), pf, dv[dt], 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans<DH>(img0, 32 * qi + 16 * s2, 32 * dt, hi, q16, i16), dsf, dk[dt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (kg < p.L) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        store_frag_T(p.dk, p.ld_dqkv, (long)b * p.L + kg, h * DH + 32 * dt, hi, dk[dt], 1.0f, DH - 32 * dt);
+        store_frag_T(p.dv, p.ld_dqkv, (long)b * p.L + kg, h * DH + 32 * dt, hi, dv[dt], 1.0f, DH - 32 * dt);
+      }
+    }
+  }
+}
+
 constexpr int ATTN_MAX_DEVICES = 64;
 
 template <int NKT, int DH, bool CAUSAL>
@@ -470,9 +760,34 @@ int launch_bwd(const AttnArgs& a, hipStream_t st) {
   return a.causal ? launch_bwd_c<NKT, DH, true>(a, st) : launch_bwd_c<NKT, DH, false>(a, st);
 }
 
+template <int DH, bool CAUSAL, bool BWD>
+int launch_long(const AttnArgs& a, hipStream_t st) {
+  const int lds = 2 * LONG_CT * 32 * HD<DH>::RB + (BWD ? 3 * LONG_LMAX * 4 : 0);
+  const void* fn = BWD ? (const void*)attn_bwd_long_kernel<DH, CAUSAL> : (const void*)attn_fwd_long_kernel<DH, CAUSAL>;
+  static std::once_flag once[ATTN_MAX_DEVICES];
+  static int rc_dev[ATTN_MAX_DEVICES];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ATTN_MAX_DEVICES) { clipa_set_error("attention: bad device"); return CLIPA_ERR_LAUNCH; }
+  std::call_once(once[dev], [&]() {
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    rc_dev[dev] = 0;
+    if (e != hipSuccess) { clipa_set_error("attention (long) attr: %s", hipGetErrorString(e)); rc_dev[dev] = CLIPA_ERR_LAUNCH; }
+  });
+  if (rc_dev[dev]) return rc_dev[dev];
+  const dim3 grid((unsigned)((long)a.B * a.H));
+  if (BWD) hipLaunchKernelGGL((attn_bwd_long_kernel<DH, CAUSAL>), grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((attn_fwd_long_kernel<DH, CAUSAL>), grid, dim3(256), lds, st, a);
+  return clipa_check_launch(BWD ? "attn_bwd_long" : "attn_fwd_long");
+}
+template <bool BWD>
+int dispatch_long(const AttnArgs& a, int64_t dh, hipStream_t st) {
+  if (dh == 80) return a.causal ? launch_long<80, true, BWD>(a, st) : launch_long<80, false, BWD>(a, st);
+  return a.causal ? launch_long<64, true, BWD>(a, st) : launch_long<64, false, BWD>(a, st);
+}
+
 int check_args(int64_t B, int64_t H, int64_t L, int64_t dh, int64_t ld_qkv, int64_t ld_o) {
   if (dh != 64 && dh != 80) { clipa_set_error("attention: head dim %ld unsupported (64 and 80 only)", (long)dh); return CLIPA_ERR_ARG; }
-  if (L <= 0 || L > 288) { clipa_set_error("attention: L=%ld outside (0, 288]", (long)L); return CLIPA_ERR_ARG; }
+  if (L <= 0 || L > LONG_LMAX) { clipa_set_error("attention: L=%ld outside (0, %d]", (long)L, LONG_LMAX); return CLIPA_ERR_ARG; }
   if (ld_qkv % 8 != 0 || ld_o % 8 != 0) { clipa_set_error("attention: row strides must be multiples of 8 elements"); return CLIPA_ERR_ARG; }
   if (B * H <= 0 || B * H > 0x7fffffffL) { clipa_set_error("attention: bad B*H"); return CLIPA_ERR_ARG; }
   return 0;
@@ -501,6 +816,7 @@ extern "C" int clipa_attention_fwd(const void* q, const void* k, const void* v, 
   a.q = (const char*)q; a.k = (const char*)k; a.v = (const char*)v; a.ld_qkv = ld_qkv;
   a.o = (char*)out; a.ld_o = ld_o; a.B = (int)B; a.H = (int)H; a.L = (int)L; a.scale = scale; a.causal = causal;
   a.stats = stats;
+  if (L > 288) return dispatch_long<false>(a, dh, (hipStream_t)stream);
   ATTN_DISPATCH(launch_fwd, dh, a, (hipStream_t)stream)
 }
 
@@ -518,5 +834,6 @@ extern "C" int clipa_attention_bwd(const void* q, const void* k, const void* v, 
   a.dq = (char*)dq; a.dk = (char*)dk; a.dv = (char*)dv; a.ld_dqkv = ld_dqkv;
   a.B = (int)B; a.H = (int)H; a.L = (int)L; a.scale = scale; a.causal = causal;
   a.stats = const_cast<float*>(stats);
+  if (L > 288) return dispatch_long<true>(a, dh, (hipStream_t)stream);
   ATTN_DISPATCH(launch_bwd, dh, a, (hipStream_t)stream)
 }

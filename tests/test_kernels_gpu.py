@@ -241,6 +241,23 @@ def test_attention(B, H, L, causal, dh):
 
 
 @pytest.mark.parametrize("dh", [64, 80])
+@pytest.mark.parametrize("B,H,L,causal", [(2, 2, 577, False), (1, 3, 401, False), (1, 2, 300, True), (1, 1, 1024, False)])
+def test_attention_long_sequences(B, H, L, causal, dh):
+    """288 < L <= 1024 (the 336-px / 14-px-patch stage of CLIPA-v2: 577 tokens; ViT-L-16-320: 401): keys / queries
+    stream through LDS in 256-row chunks, online softmax in the forward - same oracle, same tolerances."""
+    D = dh * H
+    qkv = rnd(B * L, 3 * D, seed=130 + L, scale=1.2)
+    dout = rnd(B * L, D, seed=131 + L)
+    x = qkv.double().reshape(B, L, 3 * D).requires_grad_(True)
+    o = O.attention(x, H, causal)
+    o.backward(dout.double().reshape(B, L, D))
+    got, stats = ops().attention_fwd(qkv.to(DEV), B, L, H, causal, want_stats=True)
+    check("fwd", got.reshape(B, L, D), o, 2 ** -6, 8e-3)
+    dq = ops().attention_bwd(qkv.to(DEV), got, dout.to(DEV), stats, B, L, H, causal)
+    check("dqkv", dq.reshape(B, L, 3 * D), x.grad, 2 ** -5, 2e-2)
+
+
+@pytest.mark.parametrize("dh", [64, 80])
 def test_attention_reads_packed_projection_in_place(dh):
     """q/k/v are column blocks of a wider buffer (row stride != 3D) - no head-major copy is made."""
     B, H, L = 2, 2, 50

@@ -244,3 +244,31 @@ def test_full_size_batch_properties():
         assert (f.norm(dim=-1) - 1).abs().max() < 1e-2           # bf16 features
         assert torch.equal(full[k][pick], small[k]), k           # row-major token matrix: no cross-sample mixing
     assert abs(float(loss) - math.log(B)) < 0.5
+
+
+def test_zero_shot_classifier_and_logits_match_oracle():
+    """training/zero_shot.py:29-90 through the engine: per-class prompt ensembles -> classifier, image logits, top-k.
+    Checked against the same recipe evaluated with the fp32 oracle towers."""
+    from clipa_amd import zero_shot as Z
+    g = load_golden("cls_erf")
+    m = _engine(g).eval()
+    ctx, vocab = g.cfg["text_cfg"]["context_length"], g.cfg["text_cfg"]["vocab_size"]
+    C, T = 11, 3                                                   # 11 classes (not a multiple of 8), 3 templates each
+    _, toks = O.synthetic_batch(C * T, 16, ctx, vocab, seed=5)
+    class_ids = toks.view(C, T, ctx)
+    clf, n = Z.zero_shot_classifier(m, class_ids.to(DEV))
+    assert n == C and clf.shape[0] == 16
+    images = O.normalize_images(g.images_u8)
+    fi, _, _ = O.clip_forward(g.sd, g.ocfg, images, g.texts)
+    rows = []
+    for c in range(C):
+        dummy_img = images[:T]
+        _, ft, _ = O.clip_forward(g.sd, g.ocfg, dummy_img, class_ids[c])
+        e = ft.mean(0)
+        rows.append(e / e.norm())
+    ref_logits = 100.0 * fi @ torch.stack(rows, dim=1)
+    got = Z.zero_shot_logits(m, clf, n, g.images_u8.to(DEV)).float().cpu()
+    assert (got - ref_logits).abs().max() < 1.5, float((got - ref_logits).abs().max())     # logits of magnitude <= 100
+    tgt = ref_logits.argmax(1)
+    top1, top5 = Z.run(m, clf, n, [(g.images_u8.to(DEV), tgt.to(DEV))])
+    assert top5 == 1.0 and top1 >= 0.75
