@@ -348,87 +348,6 @@ __global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const void* __re
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// K18: row-wise cross-entropy of fp32 logits with label = label0 + row (loss.py:115-126,152-155),
-// plus its gradient dlogits = gscale * (softmax - onehot) in bf16 and the per-row terms of
-// d loss / d logit_scale: sum_j dlogits_j * logits_j (divided by logit_scale on the host).
-__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ raw, long ld, int N, long label0,
-                                                      float gscale, const float* __restrict__ scale_ptr,
-                                                      unsigned short* __restrict__ dlogits, long ldd,
-                                                      float* __restrict__ loss_rows, float* __restrict__ dscale_rows) {
-  // logits = s * raw with s read from DEVICE memory (exp(logit_scale) never visits the host); columns >= N of the
-  // padded row (ld, ldd are multiples of 8) do not exist: they are skipped here and written as zero gradients.
-  __shared__ float red[4];
-  __shared__ float bc;
-  const long r = blockIdx.x;
-  const float* row = raw + (size_t)r * ld;
-  const float s = scale_ptr ? scale_ptr[0] : 1.0f;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int N4 = (N + 3) & ~3;
-  float mx = -3.0e38f;
-  for (int j = tid * 4; j < N4; j += 1024) {
-    const float4 v = *(const float4*)(row + j);
-    const float l4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (j + e < N) mx = fmaxf(mx, l4[e] * s);
-  }
-  mx = wave_max(mx);
-  if (lane == 0) red[wv] = mx;
-  __syncthreads();
-  if (tid == 0) bc = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  __syncthreads();
-  mx = bc;
-  float sum = 0.f;
-  for (int j = tid * 4; j < N4; j += 1024) {
-    const float4 v = *(const float4*)(row + j);
-    const float l4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (j + e < N) sum += __expf(l4[e] * s - mx);
-  }
-  sum = wave_sum(sum);
-  __syncthreads();
-  if (lane == 0) red[wv] = sum;
-  __syncthreads();
-  if (tid == 0) bc = red[0] + red[1] + red[2] + red[3];
-  __syncthreads();
-  sum = bc;
-  const float inv = 1.0f / sum;
-  const long label = label0 + r;
-  float ds = 0.f;
-  for (int j = tid * 4; j < N4; j += 1024) {
-    const float4 v = *(const float4*)(row + j);
-    const float l4[4] = {v.x, v.y, v.z, v.w};
-    float g[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float pr = (j + e < N) ? __expf(l4[e] * s - mx) * inv : 0.f;
-      if ((long)(j + e) == label) pr -= 1.0f;
-      g[e] = pr * gscale;                 // d loss / d logit
-      ds += g[e] * l4[e];                 // d loss / d s  = sum_j dlogit_j * raw_j
-      g[e] *= s;                          // d loss / d raw: what the four gradient GEMMs consume
-    }
-    if (dlogits) {
-      u32x2 w;
-      w[0] = pack2bf(g[0], g[1]);
-      w[1] = pack2bf(g[2], g[3]);
-      *(u32x2*)(dlogits + (size_t)r * ldd + j) = w;
-    }
-  }
-  if (dlogits && tid == 0) {              // zero the pad columns N4 .. ldd_pad (ldd is a multiple of 8, N4 of 4)
-    if (N4 < ((N + 7) & ~7)) *(u32x2*)(dlogits + (size_t)r * ldd + N4) = u32x2{0u, 0u};
-  }
-  ds = wave_sum(ds);
-  __syncthreads();
-  if (lane == 0) red[wv] = ds;
-  __syncthreads();
-  if (tid == 0) {
-    loss_rows[r] = logf(sum) + mx - row[label] * s;
-    if (dscale_rows) dscale_rows[r] = red[0] + red[1] + red[2] + red[3];
-  }
-}
-
 // out[0] = scale * sum_i in[i]  (single workgroup; n is small)
 __global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ in, float* __restrict__ out, long n, float scale, int accumulate) {
   __shared__ float red[4];
@@ -630,17 +549,6 @@ extern "C" int clipa_activation_fwd(const void* in, void* out, int64_t n, int ac
   else if (act == ACT_QUICK_GELU) hipLaunchKernelGGL(activation_kernel<ACT_QUICK_GELU>, dim3(grid), dim3(256), 0, st, (const unsigned short*)in, (unsigned short*)out, (long)(n / 8));
   else { clipa_set_error("activation_fwd: unknown activation %d", act); return CLIPA_ERR_ARG; }
   return clipa_check_launch("activation_fwd");
-}
-
-extern "C" int clipa_ce_rows(const float* raw, int64_t rows, int64_t N, int64_t ld, int64_t label0, float gscale,
-                             const float* scale, void* dlogits_bf16, int64_t ldd, float* loss_rows, float* dscale_rows,
-                             void* stream) {
-  const int64_t N8 = (N + 7) & ~(int64_t)7;
-  if (ld % 4 != 0 || ld < N8 || (dlogits_bf16 && (ldd % 4 != 0 || ldd < N8))) { clipa_set_error("ce_rows: ld, ldd must be multiples of 4 and >= N rounded up to 8"); return CLIPA_ERR_ARG; }
-  if (label0 < 0 || label0 + rows > N) { clipa_set_error("ce_rows: labels [%ld, %ld) outside [0, %ld)", (long)label0, (long)(label0 + rows), (long)N); return CLIPA_ERR_ARG; }
-  if (rows <= 0) return CLIPA_OK;
-  hipLaunchKernelGGL(ce_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, raw, (long)ld, (int)N, (long)label0, gscale, scale, (unsigned short*)dlogits_bf16, (long)ldd, loss_rows, dscale_rows);
-  return clipa_check_launch("ce_rows");
 }
 
 extern "C" int clipa_sum_scale(const float* in, float* out, int64_t n, float scale, int accumulate, void* stream) {

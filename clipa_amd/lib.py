@@ -43,7 +43,9 @@ SIGNATURES = {
     "clipa_cast_bf16_to_f32": (_I32, [_P, _P, _I64, _P]),
     "clipa_transpose_to_bf16": (_I32, [_P, _I32, _P, _I64, _I64, _I64, _I64, _P]),
     "clipa_activation_fwd": (_I32, [_P, _P, _I64, _I32, _P]),
-    "clipa_ce_rows": (_I32, [_P, _I64, _I64, _I64, _I64, _F, _P, _P, _I64, _P, _P, _P]),
+    "clipa_simce_workspace": (_I64, [_I64, _I64]),
+    "clipa_simce_fwd": (_I32, [_P, _P, _I64, _I64, _I64, _I64, _I64, _P, _I64, _P, _P, _P, _I64, _P]),
+    "clipa_simce_bwd": (_I32, [_P, _P, _I64, _I64, _I64, _I64, _I64, _P, _I64, _F, _P, _P, _I64, _P, _P, _I64, _P]),
     "clipa_sum_scale": (_I32, [_P, _P, _I64, _F, _I32, _P]),
     "clipa_adamw": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _F, _F, _F, _F, _F, _I64, _F, _P]),
     "clipa_adamw_multi": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _F, _F, _F, _F, _F, _I64, _F, _P, _I32, _F, _F, _P]),

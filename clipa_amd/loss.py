@@ -13,10 +13,11 @@ MI355X mapping.
   the text gather is exposed.  (The reference gathers both serially after both towers, loss.py:73-76.)
 * Backward of the differentiable gather = ONE reduce-scatter(SUM) of the fused [W*B, 2E] fp32 gradient - the
   semantics of torch.distributed.nn.all_gather's backward used by the reference.
-* The similarity GEMMs produce the UNSCALED I.T^T; exp(logit_scale) stays in device memory and is applied inside the
-  cross-entropy kernel (`ops.ce_rows(scale=...)`), which also folds it into the bf16 d loss / d raw the four gradient
-  GEMMs consume - no `.item()`, no host sync per step.  Batches that are not multiples of 8 are zero-padded to the
-  GEMM granularity; the pad columns are excluded from the softmax inside the kernel.
+* Similarity GEMM and cross-entropy are ONE kernel pair (`ops.simce`, csrc/simce.hip): the GEMM epilogue reduces each
+  logits tile to per-row (max, sum exp) partials, the fp32 [B, W*B] logits never reach HBM; the backward re-runs the
+  GEMM and emits the bf16 d loss / d (I.T^T) that the four gradient GEMMs consume.  exp(logit_scale) stays in device
+  memory and is applied inside those kernels - no `.item()`, no host sync per step.  Batches that are not multiples
+  of 8 are zero-padded to the GEMM granularity; the pad columns are excluded from the softmax inside the kernel.
 * Host-side glue that stays in torch: `torch.cat` / `+` of the [B, E] gradient pieces in backward (a few MB).
 """
 import torch
@@ -130,12 +131,11 @@ class ClipLossFn(torch.autograd.Function):
             i_rows, t_rows, label0 = ib, tb, (B * rank if world_size > 1 else 0)
         R, N = i_rows.shape[0], i_all.shape[0]
         i_all8, t_all8 = _pad_rows8(i_all), _pad_rows8(t_all)
-        raw_i = ops.gemm_nt(i_rows, t_all8, out_f32=True)                 # [R, N8] unscaled similarities
-        raw_t = ops.gemm_nt(t_rows, i_all8, out_f32=True)
         need_grad = any(ctx.needs_input_grad[:3])
         gs = 0.5 / R
-        li, dli, dsi = ops.ce_rows(raw_i, N, label0, gs, scale=s_dev, want_grad=need_grad)
-        lt, dlt, dst = ops.ce_rows(raw_t, N, label0, gs, scale=s_dev, want_grad=need_grad)
+        # fused similarity GEMM + cross-entropy: the [R, N] fp32 logits never reach HBM (K17 + K18)
+        li, dli, dsi = ops.simce(i_rows, t_all8, N, label0, gs, scale=s_dev, want_grad=need_grad)
+        lt, dlt, dst = ops.simce(t_rows, i_all8, N, label0, gs, scale=s_dev, want_grad=need_grad)
         loss = ops.sum_scale(li, gs)
         ops.sum_scale(lt, gs, out=loss, accumulate=True)
         if need_grad:

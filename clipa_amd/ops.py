@@ -399,22 +399,34 @@ def activation_fwd(x, act):
     return out
 
 
-def ce_rows(raw, n_valid, label0, gscale, scale=None, want_grad=True):
-    """Row-wise CE of s * raw[:, :n_valid] with labels label0 + row; s = scale[0] read on the device (None = 1).
-    raw f32 [R, ld] with ld >= n_valid rounded up to 8.  Returns loss_rows f32 [R], d loss / d raw bf16 [R, ld8]
-    (pad columns zero) | None, and the per-row d loss / d s."""
-    _chk(raw, f32, "raw", 2)
-    R = raw.shape[0]
-    n8 = (n_valid + 7) // 8 * 8
-    if raw.stride(0) < n8:
-        raise RuntimeError(f"ce_rows: row stride {raw.stride(0)} < {n8}")
-    loss_rows = torch.empty(R, device=raw.device, dtype=f32)
-    dscale_rows = torch.empty(R, device=raw.device, dtype=f32)
-    dl = torch.empty((R, n8), device=raw.device, dtype=bf16) if want_grad else None
+def simce(rows, cols, n_valid, label0, gscale, scale=None, want_grad=True):
+    """Fused similarity + cross-entropy (InfoNCE): logits = s * rows @ cols[:n_valid]^T, labels label0 + row; s =
+    scale[0] read on the device (None = 1).  rows [R,E], cols [>= n_valid, E] bf16.  Returns loss_rows f32 [R], the bf16
+    d loss / d (rows @ cols^T) [R, n8] (n8 = n_valid rounded up to 8, pad columns zero) | None, and the per-row
+    d loss / d s.  The fp32 logits never exist in HBM (the backward re-runs the similarity GEMM)."""
+    _chk(rows, bf16, "rows", 2)
+    _chk(cols, bf16, "cols", 2)
+    rows, lda = _rowmajor(rows)
+    cols, ldb = _rowmajor(cols)
+    R, E = rows.shape
+    if cols.shape[1] != E or cols.shape[0] < n_valid:
+        raise RuntimeError(f"simce: cols {tuple(cols.shape)} does not cover {n_valid} x {E}")
     if scale is not None:
         _chk(scale, f32, "scale")
-    lib.call("clipa_ce_rows", _p(raw), R, n_valid, raw.stride(0), label0, float(gscale), _p(scale), _p(dl), n8, _p(loss_rows),
-             _p(dscale_rows), _stream())
+    n8 = (n_valid + 7) // 8 * 8
+    wsb = lib.query("clipa_simce_workspace", R, n_valid)
+    ws = torch.empty(max(wsb, 4) // 4, device=rows.device, dtype=f32)
+    lse = torch.empty(R, device=rows.device, dtype=f32)
+    loss_rows = torch.empty(R, device=rows.device, dtype=f32)
+    with _Timed("simce", 2.0 * R * n_valid * E * (2 if want_grad else 1)):
+        lib.call("clipa_simce_fwd", _p(rows), _p(cols), R, n_valid, E, lda, ldb, _p(scale), label0, _p(lse), _p(loss_rows), _p(ws),
+                 wsb, _stream())
+        if not want_grad:
+            return loss_rows, None, None
+        dl = torch.empty((R, n8), device=rows.device, dtype=bf16)
+        dscale_rows = torch.empty(R, device=rows.device, dtype=f32)
+        lib.call("clipa_simce_bwd", _p(rows), _p(cols), R, n_valid, E, lda, ldb, _p(scale), label0, float(gscale), _p(lse), _p(dl),
+                 n8, _p(dscale_rows), _p(ws), wsb, _stream())
     return loss_rows, dl, dscale_rows
 
 

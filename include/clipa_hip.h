@@ -123,14 +123,19 @@ int clipa_transpose_to_bf16(const void* in, int in_f32, void* out, int64_t R, in
                             int64_t ldo, void* stream);
 /* out = act(in) elementwise, bf16 (MLP activation re-materialised from the kept pre-activation) */
 int clipa_activation_fwd(const void* in, void* out, int64_t n, int act, void* stream);
-/* F.cross_entropy(s * raw, arange + label0) rows (loss.py:115-126,152-155) on the UNSCALED similarities raw = I.T^T:
- * the scale s = exp(logit_scale) is read from device memory (`scale`, may be NULL = 1), so the loss never syncs the
- * host.  Only the first N columns of a row exist (ld, ldd >= N rounded up to 8: the GEMMs want multiples of 8).
- * Outputs: per-row loss; bf16 d loss / d raw = s * gscale * (softmax - onehot), pad columns zeroed; per-row
- * d loss / d s = sum_j gscale * (softmax - onehot)_j * raw_j. */
-int clipa_ce_rows(const float* raw, int64_t rows, int64_t N, int64_t ld, int64_t label0, float gscale,
-                  const float* scale, void* dlogits_bf16, int64_t ldd, float* loss_rows, float* dscale_rows,
-                  void* stream);
+/* Fused similarity + cross-entropy of the InfoNCE loss (loss.py:128-155): logits = s * rows . cols^T (rows [R,E],
+ * cols [N,E] bf16, s = exp(logit_scale) read from DEVICE memory, NULL = 1), labels label0 + r.  The [R,N] fp32 logits are
+ * never written: the forward GEMM's epilogue keeps per-tile (max, sum exp) partials, merged into lse[R] and
+ * loss_rows[R] = lse - logit[label]; the backward re-runs the GEMM and writes the bf16 gradient
+ * d loss / d (rows.cols^T) = s * gscale * (softmax - onehot) ([R, ldd], ldd >= N rounded up to 8, pad columns zero) plus
+ * dscale_rows[R] = per-row d loss / d s.  Workspace: clipa_simce_workspace(R, N) bytes for either call. */
+int64_t clipa_simce_workspace(int64_t R, int64_t N);
+int clipa_simce_fwd(const void* rows, const void* cols, int64_t R, int64_t N, int64_t E, int64_t lda, int64_t ldb,
+                    const float* scale, int64_t label0, float* lse, float* loss_rows, void* workspace,
+                    int64_t workspace_bytes, void* stream);
+int clipa_simce_bwd(const void* rows, const void* cols, int64_t R, int64_t N, int64_t E, int64_t lda, int64_t ldb,
+                    const float* scale, int64_t label0, float gscale, const float* lse, void* dlogits_bf16,
+                    int64_t ldd, float* dscale_rows, void* workspace, int64_t workspace_bytes, void* stream);
 int clipa_sum_scale(const float* in, float* out, int64_t n, float scale, int accumulate, void* stream);
 
 /* AdamW over one flat tensor (training/main.py:318-326 torch.optim.AdamW + train.py:285-286 clamp is

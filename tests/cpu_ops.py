@@ -168,21 +168,22 @@ def activation_fwd(x, act):
     return _act(x.float(), act).to(bf16)
 
 
-def ce_rows(raw, n_valid, label0, gscale, scale=None, want_grad=True):
-    R = raw.shape[0]
+def simce(rows, cols, n_valid, label0, gscale, scale=None, want_grad=True):
+    R = rows.shape[0]
     n8 = (n_valid + 7) // 8 * 8
     s = float(scale.reshape(-1)[0]) if scale is not None else 1.0
-    logits = raw[:, :n_valid].float() * s
+    raw = rows.float() @ cols[:n_valid].float().T
+    logits = raw * s
     labels = torch.arange(R) + label0
     loss_rows = torch.logsumexp(logits, dim=1) - logits[torch.arange(R), labels]
+    if not want_grad:
+        return loss_rows, None, None
     p = torch.softmax(logits, dim=1)
     p[torch.arange(R), labels] -= 1.0
     g = p * gscale
-    dl = None
-    if want_grad:
-        dl = torch.zeros((R, n8), dtype=bf16)
-        dl[:, :n_valid] = (g * s).to(bf16)
-    return loss_rows, dl, (g * raw[:, :n_valid].float()).sum(1)
+    dl = torch.zeros((R, n8), dtype=bf16)
+    dl[:, :n_valid] = (g * s).to(bf16)
+    return loss_rows, dl, (g * raw).sum(1)
 
 
 def sum_scale(x, scale, out=None, accumulate=False):

@@ -23,21 +23,22 @@ def _cpu_ops():
     o.gemm_nt = lambda a, b, alpha=1.0, out_f32=True: (a.float() @ b.float().T) * alpha
     o.gemm_tn = lambda p, q, dt=f32: (p.float().T @ q.float()).to(dt)
 
-    def ce_rows(raw, n_valid, label0, gscale, scale=None, want_grad=True):
-        R = raw.shape[0]
+    def simce(rows, cols, n_valid, label0, gscale, scale=None, want_grad=True):
+        R = rows.shape[0]
         n8 = (n_valid + 7) // 8 * 8
         s = float(scale.reshape(-1)[0]) if scale is not None else 1.0
-        logits = raw[:, :n_valid].float() * s
+        raw = rows.float() @ cols[:n_valid].float().T
+        logits = raw * s
         labels = torch.arange(R) + label0
         loss_rows = torch.logsumexp(logits, dim=1) - logits[torch.arange(R), labels]
+        if not want_grad:
+            return loss_rows, None, None
         p = torch.softmax(logits, dim=1)
         p[torch.arange(R), labels] -= 1.0
         g = p * gscale
-        dl = None
-        if want_grad:
-            dl = torch.zeros((R, n8), dtype=bf16)
-            dl[:, :n_valid] = (g * s).to(bf16)
-        return loss_rows, dl, (g * raw[:, :n_valid].float()).sum(1)
+        dl = torch.zeros((R, n8), dtype=bf16)
+        dl[:, :n_valid] = (g * s).to(bf16)
+        return loss_rows, dl, (g * raw).sum(1)
 
     def sum_scale(x, scale, out=None, accumulate=False):
         v = x.sum() * scale
@@ -46,7 +47,7 @@ def _cpu_ops():
         out.copy_(out + v if accumulate else v)
         return out
 
-    o.ce_rows, o.sum_scale = ce_rows, sum_scale
+    o.simce, o.sum_scale = simce, sum_scale
     return o
 
 

@@ -366,24 +366,31 @@ def test_assemble_embed_pool_l2norm_colsum_cast():
     check("to_f32", o.to_f32(w.to(bf16).to(DEV)), w.to(bf16).float(), 0, 0)
 
 
-@pytest.mark.parametrize("R,N,label0", [(8, 8, 0), (16, 64, 48), (300, 4096, 1000)])
-def test_cross_entropy_rows(R, N, label0):
-    """logits = s * raw with the scale in device memory; N need not be a multiple of 8 (pad columns are ignored)."""
+@pytest.mark.parametrize("R,N,E,label0", [(8, 8, 64, 0), (4, 4, 32, 0), (16, 64, 128, 48), (300, 4100, 768, 1000), (520, 520, 512, 0)])
+def test_fused_similarity_cross_entropy(R, N, E, label0):
+    """ops.simce = similarity GEMM + cross-entropy in one kernel pair (fp32 logits never written): loss rows, the bf16
+    gradient w.r.t. the raw similarities and d loss / d s against fp64; N need not be a multiple of 8 or of the tile."""
+    g = torch.Generator().manual_seed(R + N)
+    rows = torch.nn.functional.normalize(torch.randn(R, E, generator=g), dim=1).to(bf16)
+    cols = torch.nn.functional.normalize(torch.randn(N, E, generator=g), dim=1).to(bf16)
     n8 = (N + 7) // 8 * 8
-    raw = rnd(R, n8, seed=80, dtype=f32, scale=0.3)
-    s = 13.7
-    lr = (raw[:, :N].double() * s).requires_grad_(True)
+    cols8 = torch.zeros(n8, E, dtype=bf16)
+    cols8[:N] = cols
+    s = 14.3
+    raw = (rows.double() @ cols.double().T).requires_grad_(True)
     labels = torch.arange(R) + label0
-    per = torch.nn.functional.cross_entropy(lr, labels, reduction="none")
+    per = torch.nn.functional.cross_entropy(raw * s, labels, reduction="none")
     gs = 0.5 / R
     (per.sum() * gs).backward()
     scale = torch.tensor([s], device=DEV, dtype=f32)
-    loss_rows, dl, ds = ops().ce_rows(raw.to(DEV), N, label0, gs, scale=scale)
-    check("loss rows", loss_rows, per, 1e-5, 2e-5)
-    check("d loss / d raw", dl[:, :N], lr.grad * s, 2 ** -7, 1e-7)
+    loss_rows, dl, ds = ops().simce(rows.to(DEV), cols8.to(DEV), N, label0, gs, scale=scale)
+    check("loss rows", loss_rows, per.detach(), 1e-4, 2e-4)
+    check("d loss / d raw", dl[:, :N], raw.grad, 2 ** -7, 1e-6)
     assert not dl[:, N:].float().abs().any(), "pad columns of the gradient must be zero"
-    check("d loss / d s rows", ds, (lr.grad * raw[:, :N].double()).sum(1), 1e-3, 1e-5)
-    check("sum", ops().sum_scale(loss_rows, gs), per.sum() * gs, 1e-5, 1e-6)
+    check("d loss / d s rows", ds, (raw.grad / s * raw.detach()).sum(1), 2e-3, 2e-5)
+    only_loss, none_dl, _ = ops().simce(rows.to(DEV), cols8.to(DEV), N, label0, gs, scale=scale, want_grad=False)
+    assert none_dl is None and torch.equal(only_loss, loss_rows)
+    check("sum", ops().sum_scale(loss_rows, gs), per.detach().sum() * gs, 1e-4, 1e-5)
 
 
 @pytest.mark.parametrize("pdt,gdt", [(f32, f32), (bf16, bf16)])
