@@ -7,6 +7,238 @@
 //   gemm_nt6  256x128x32 tile, 4 waves, two persistent workgroups per CU                            (variant 13)
 //   gemm_nt7  256x256 tile, K step 32, five-slot ring with four steps in flight, counted vmcnt      (variant 14)
 
+//   gemm_ntd  direct (MFMA-fragment-layout) epilogue on the production tile                         (variant 12)
+
+// ------------------------------------------------------------------------------------------------
+// DIRECT epilogue (gemm_ntd / gemm_nt6).  LDS row r = 16*bj + i of a wave's 64 B-image rows (MFMA row i of its
+// n block bj) is filled, at DMA time, with tile feature
+//     bperm(r) = 32*(bj>>1) + 8*(i>>2) + 4*(bj&1) + (i&3).
+// An MFMA leaves rows 4g..4g+3 of block bj in lane (c = lane & 15, g = lane >> 4), so for s = 0, 1 that lane owns
+// the 8 CONSECUTIVE features 32*s + 8*g + 0..7 (blocks 2s and 2s+1) of token row 16*ai + c:
+//     acc[bj][ai][r]  ==  C[mw + 16*ai + c][nw + 32*(bj>>1) + 8*g + 4*(bj&1) + r]
+// One 16-byte buffer store per (ai, s): 16 rows x 64 contiguous bytes per instruction, no LDS transpose, no
+// barrier.  Row bounds ride the buffer descriptor (the row offset sits in the bounds-checked VGPR offset: rows >= M
+// are dropped / read as zero), the column bound is a lane
+// predicate.  Rounding points are those of the LDS-window epilogue (and of the reference in bf16 mode: a Linear's
+// output is rounded to bf16 before the activation / the residual add sees it).
+__device__ __forceinline__ int bperm(int r64) {
+  const int bj = r64 >> 4, i = r64 & 15;
+  return 32 * (bj >> 1) + 8 * (i >> 2) + 4 * (bj & 1) + (i & 3);
+}
+
+template <int EPI, bool HAS_C2, int ACT>
+__device__ __forceinline__ void store_direct_act(const NTArgs& p, const f32x4v (&acc)[4][8], int mw, int nw, int lane) {
+  constexpr bool NEED_AUX = (EPI == CLIPA_EPI_ADD || EPI == CLIPA_EPI_DACT);
+  const int rows = min(128, p.M - mw);
+  if (rows <= 0) return;                                  // wave-uniform
+  const int c = lane & 15, g = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rsC = make_rsrc(p.C + (size_t)mw * p.ldc * 2, (unsigned)((long)rows * p.ldc * 2));
+  __amdgpu_buffer_rsrc_t rsC2 = rsC, rsX = rsC;
+  if constexpr (HAS_C2) rsC2 = make_rsrc(p.C2 + (size_t)mw * p.ldc * 2, (unsigned)((long)rows * p.ldc * 2));
+  if constexpr (NEED_AUX) rsX = make_rsrc(p.aux + (size_t)mw * p.ldaux * 2, (unsigned)((long)rows * p.ldaux * 2));
+  const int stepC = (int)(16 * p.ldc * 2), stepX = (int)(16 * p.ldaux * 2);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int n = nw + 32 * s + 8 * g;
+    const bool nok = n < p.N;
+    const int voffC = (int)((c * p.ldc + n) * 2);
+    float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.bias && nok) {
+      const float4 x = *(const float4*)(p.bias + n), y = *(const float4*)(p.bias + n + 4);
+      bb[0] = x.x; bb[1] = x.y; bb[2] = x.z; bb[3] = x.w; bb[4] = y.x; bb[5] = y.y; bb[6] = y.z; bb[7] = y.w;
+    }
+    u32x4 av[8];
+    if constexpr (NEED_AUX) {
+      const int voffX = (int)((c * p.ldaux + n) * 2);
+#pragma unroll
+      for (int ai = 0; ai < 8; ++ai) {
+        av[ai] = u32x4{0, 0, 0, 0};
+        if (nok) av[ai] = __builtin_amdgcn_raw_buffer_load_b128(rsX, voffX + ai * stepX, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int ai = 0; ai < 8; ++ai) {
+      float f[8], a[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        f[r] = acc[2 * s][ai][r] * p.alpha + bb[r];
+        f[4 + r] = acc[2 * s + 1][ai][r] * p.alpha + bb[4 + r];
+      }
+      u32x4 v = pack8(f);
+      if constexpr (EPI == CLIPA_EPI_ACT) {
+        if constexpr (HAS_C2) {
+          if (nok && !((p.abl & 1) && v[1] != 0x12345u)) __builtin_amdgcn_raw_buffer_store_b128(v, rsC2, voffC + ai * stepC, 0, 0);
+        }
+        unpack8(v, f);
+        epi_apply<ACT>(CLIPA_EPI_ACT, f, a);
+        v = pack8(f);
+      } else if constexpr (EPI == CLIPA_EPI_ADD) {
+        unpack8(v, f);
+        unpack8(av[ai], a);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] += a[i];
+        v = pack8(f);
+      } else if constexpr (EPI == CLIPA_EPI_DACT) {
+        unpack8(v, f);
+        unpack8(av[ai], a);
+        epi_apply<ACT>(CLIPA_EPI_DACT, f, a);
+        v = pack8(f);
+      }
+      if (nok && !((p.abl & 1) && v[0] != 0x12345u)) __builtin_amdgcn_raw_buffer_store_b128(v, rsC, voffC + ai * stepC, 0, 0);
+    }
+  }
+}
+
+template <int EPI, bool HAS_C2>
+__device__ __forceinline__ void store_direct(const NTArgs& p, const f32x4v (&acc)[4][8], int mw, int nw, int lane) {
+  if constexpr (EPI == CLIPA_EPI_ACT || EPI == CLIPA_EPI_DACT) {
+    if (p.act == ACT_GELU_ERF) store_direct_act<EPI, HAS_C2, ACT_GELU_ERF>(p, acc, mw, nw, lane);
+    else if (p.act == ACT_GELU_TANH) store_direct_act<EPI, HAS_C2, ACT_GELU_TANH>(p, acc, mw, nw, lane);
+    else store_direct_act<EPI, HAS_C2, ACT_QUICK_GELU>(p, acc, mw, nw, lane);
+  } else {
+    store_direct_act<EPI, HAS_C2, ACT_GELU_ERF>(p, acc, mw, nw, lane);
+  }
+}
+
+// keep the accumulators live without storing them (experiment flag 2: main loop alone)
+__device__ __forceinline__ void sink_acc(const NTArgs& p, const f32x4v (&acc)[4][8], int tid) {
+  float t = 0.f;
+#pragma unroll
+  for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+    for (int ai = 0; ai < 8; ++ai) t += acc[bj][ai][0] + acc[bj][ai][1] + acc[bj][ai][2] + acc[bj][ai][3];
+  if (t == 1.2345e-30f) ((float*)p.C)[tid] = t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_ntd: the 256x256x64 tile / 8 waves / 2-slot ring / 16x16x32 main loop of gemm_nt2<bf16, M16> with
+//   * the operand DMA issued from inline asm (hidden from hipcc: no compiler vmcnt in front of LDS reads),
+//   * the DIRECT epilogue above (B image rows permuted at DMA time),
+//   * a ring hand-off that does not wait for the epilogue's stores: the first K tile of the next output tile is
+//     waited for BEFORE the stores are issued (`vmcnt(0)` at the top of the epilogue: only DMA is outstanding
+//     there), so the first main-loop iteration after an epilogue needs a barrier only; the stores have that
+//     iteration (plus the epilogue's remainder) to drain before the next `vmcnt(0)`.
+template <int EPI, bool HAS_C2>
+__global__ __launch_bounds__(NTHREADS) void gemm_ntd_kernel(NTArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+  const int tilesN = (p.N + BN - 1) / BN;
+  const int tilesM = (p.M + BM - 1) / BM;
+  const unsigned ntiles = (unsigned)(tilesM * tilesN);
+  const unsigned G = gridDim.x, xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+  const unsigned gx = (G - xcd + 7u) >> 3;            // workgroups on this XCD
+  const unsigned q8 = ntiles >> 3, r8 = ntiles & 7u;
+  const unsigned base = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const unsigned len = q8 + (xcd < r8 ? 1u : 0u);
+
+  // DMA piece pc = j*8 + wave = image rows 8*pc .. 8*pc+7 (128 B each); lane -> row (lane>>3), physical chunk lane&7.
+  // Image row 64*j + 8*wave + (lane>>3): its swizzle key (row>>1)&7 does not depend on j.
+  const int r8l = lane >> 3;
+  const int chunk = (lane & 7) ^ (((lane >> 4) + 4 * (wave & 1)) & 7);
+  const int kel = chunk * 8;
+  const int i16 = 8 * (wave & 1) + r8l, bjw = wave >> 1;    // B image row 64*j + 16*bjw + i16 <- feature 64*j + bperm(.)
+  const unsigned voffA = (unsigned)((wave * 8 + r8l) * p.lda * 2 + chunk * 16);
+  const unsigned voffB = (unsigned)(bperm(16 * bjw + i16) * p.ldb * 2 + chunk * 16);
+  const unsigned stepA = (unsigned)(64 * p.lda * 2), stepB = (unsigned)(64 * p.ldb * 2);
+  const int nkt = (p.K + BK - 1) / BK;
+
+  auto tile_origin = [&](unsigned t, int& m0, int& n0) {
+    const int GM = (p.abl & 8) ? 1 : 4;
+    const int per = GM * tilesN;
+    const int g = (int)t / per, r = (int)t - g * per;
+    const int gm = min(GM, tilesM - g * GM);
+    const int tn = r / gm, mm = r - tn * gm;
+    m0 = (g * GM + mm) * BM;
+    n0 = tn * BN;
+  };
+  auto srdA = [&](int m) { return make_srd(p.A + (size_t)m * p.lda * 2, (unsigned)(min(BM, p.M - m) * p.lda * 2)); };
+  auto srdB = [&](int n) { return make_srd(p.B + (size_t)n * p.ldb * 2, (unsigned)(min(BN, p.N - n) * p.ldb * 2)); };
+  auto stage = [&](unsigned buf, const u32x4 rsA, const u32x4 rsB, int k0) {
+    const unsigned oob = (k0 + kel >= p.K) ? 0x80000000u : 0u;   // K tail: push the lane past num_records -> zeros
+    const unsigned dA = lds0 + buf * STAGE_BYTES + wave * 1024, dB = dA + IMG_BYTES;
+    dma16_x4<8192>(rsA, dA, voffA | oob, (voffA + stepA) | oob, (voffA + 2 * stepA) | oob, (voffA + 3 * stepA) | oob, (unsigned)(k0 * 2));
+    dma16_x4<8192>(rsB, dB, voffB | oob, (voffB + stepB) | oob, (voffB + 2 * stepB) | oob, (voffB + 3 * stepB) | oob, (unsigned)(k0 * 2));
+  };
+
+  if (idx >= len) return;
+  unsigned it = idx;
+  int m0, n0;
+  tile_origin(base + it, m0, n0);
+  u32x4 sa = srdA(m0), sb = srdB(n0);
+  stage(0, sa, sb, 0);
+  unsigned gk = 0;        // global K-tile counter: ring slot = gk & 1
+  bool landed = false;    // K tile 0 of this output tile is already known to have landed (epilogue waited for it)
+  const int l15 = lane & 15, g4 = lane >> 4, sw16 = (l15 >> 1) & 7;
+  for (;;) {
+    const bool has_next = it + gx < len;
+    int m1 = 0, n1 = 0;
+    if (has_next) tile_origin(base + it + gx, m1, n1);
+    const u32x4 sa1 = srdA(m1), sb1 = srdB(n1);
+
+    f32x4v acc[4][8];      // [n block of 16][m block of 16]
+#pragma unroll
+    for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+      for (int ai = 0; ai < 8; ++ai) acc[bj][ai] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nkt; ++kt, ++gk) {
+      if (!(kt == 0 && landed)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      WG_BARRIER_LDS();
+      if (kt + 1 < nkt) stage((gk + 1) & 1, sa, sb, (kt + 1) * BK);
+      else if (has_next) stage((gk + 1) & 1, sa1, sb1, 0);
+      const char* sA = smem + (gk & 1) * STAGE_BYTES;
+      const char* sB = sA + IMG_BYTES;
+      // 8 sub-steps per K tile: (kk, s) = 32-wide k-step kk, A blocks 2s and 2s+1 against the four B blocks of kk
+      const char* pa = sA + (wm * 128 + l15) * 128;
+      const char* pb = sB + (wn * 64 + l15) * 128;
+      bf16x8 ga[2][2], gb[2][4];
+#pragma unroll
+      for (int bj = 0; bj < 4; ++bj) gb[0][bj] = *(const bf16x8*)(pb + bj * 2048 + ((g4 ^ sw16) << 4));
+#pragma unroll
+      for (int a = 0; a < 2; ++a) ga[0][a] = *(const bf16x8*)(pa + a * 2048 + ((g4 ^ sw16) << 4));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int kk = u >> 2, sbk = u & 3;
+        if (u < 7) {
+          const int k1 = (u + 1) >> 2, s1 = (u + 1) & 3;
+#pragma unroll
+          for (int a = 0; a < 2; ++a) ga[(u + 1) & 1][a] = *(const bf16x8*)(pa + (2 * s1 + a) * 2048 + (((4 * k1 + g4) ^ sw16) << 4));
+        }
+        if (u == 1) {
+#pragma unroll
+          for (int bj = 0; bj < 4; ++bj) gb[1][bj] = *(const bf16x8*)(pb + bj * 2048 + (((4 + g4) ^ sw16) << 4));
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+            acc[bj][2 * sbk + a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gb[kk][bj], ga[u & 1][a], acc[bj][2 * sbk + a], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+
+    // Only DMA is outstanding here (the previous epilogue's stores retired before this tile's second K tile):
+    // wait for the next tile's first K tile now, so the stores below never sit in front of a ring hand-off.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    landed = true;
+    if (p.abl & 2) sink_acc(p, acc, tid);
+    else store_direct<EPI, HAS_C2>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
+    if (!has_next) break;
+    it += gx;
+    m0 = m1;
+    n0 = n1;
+    sa = sa1;
+    sb = sb1;
+  }
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // gemm_nte = gemm_ntd with DEFERRED stores.  Measured on MI355X (profiles/r02_gemm_epilogue_experiments.md): a CU
 // moves vector stores at ~16 B/clk, a wave that issues a store while that path is busy stalls AT ISSUE, and with all

@@ -40,11 +40,10 @@ extern "C" {
 
 const char* clipa_last_error(void);
 int clipa_version(void);
-/* kernel-experiment hook (tools/gemm_round2.py, tools/tn_ab.py, tests: in-process A/B of kernels; two relaxed atomics).
- * gemm_nt variant: 0 (default) per-epilogue routing; 11 LDS-window epilogue for every bf16-output GEMM; 12 direct
- * (MFMA-fragment-layout) epilogue for every bf16-output GEMM.  Flags: 1 epilogue maths without global stores, 2 main
- * loop only, 8 row-major tile order; gemm_tn: 1024 / 2048 force the 16x16x32 / ping-pong kernel, 4096 / 8192 force
- * the slice-per-XCD / tile-per-XCD work order.  Production callers never touch it. */
+/* kernel-experiment hook (tools/tn_ab.py, tests: in-process A/B; two relaxed atomics).  gemm_nt_variant is reserved (the
+ * round-2 gemm_nt experiments live outside the library); flags: gemm_nt 2 = main loop only, 8 = row-major tile order;
+ * gemm_tn 1024 / 2048 force the 16x16x32 / ping-pong kernel, 4096 / 8192 force the slice-per-XCD / tile-per-XCD work
+ * order.  Production callers never touch it. */
 int clipa_debug_set(int gemm_nt_variant, int ablation_flags);
 
 /* C[M,N] = epi(alpha * A[M,K] . B[N,K]^T + bias[N]); A,B bf16; C bf16 (or f32 when out_f32, epi NONE).
