@@ -65,6 +65,8 @@ def _block_forward(x, P, cfg, keep):
     "medium" (light without hpre, 10 instead of 18 bytes per element of x: backward re-runs LN2 + the c_fc GEMM,
     a third of the block's forward FLOPs, and skips the other three GEMMs and attention)."""
     B, L, H, causal, act = cfg["B"], cfg["L"], cfg["H"], cfg["causal"], cfg["act"]
+    if cfg.get("fp8"):
+        return _block_forward_fp8(x, P, cfg, keep)
     h1 = ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"])
     qkv = ops.gemm_nt(h1, P["w_in"], P["b_in"])
     if keep:
@@ -85,32 +87,87 @@ def _block_forward(x, P, cfg, keep):
     return y, None
 
 
+def _lin8(xq, xs, P, name, **kw):
+    """fp8 linear: row-quantised activation (xq, xs) against the cached row-quantised weight."""
+    wq, ws = P["w8_" + name]
+    return ops.gemm_nt_f8(xq, xs, wq, ws, P["b_" + name], **kw)
+
+
+def _dlin8(dy, P, name, cfg, **kw):
+    """fp8 input gradient: quantise the incoming gradient per token, multiply with the cached quantised W^T."""
+    fmt = cfg.get("fp8_grad_fmt", ops.FMT_E4M3)
+    dq, ds = ops.quantize_rows(dy, fmt)
+    wq, ws = P["wt8_" + name]
+    return ops.gemm_nt_f8(dq, ds, wq, ws, None, fmt_a=fmt, **kw)
+
+
+def _block_forward_fp8(x, P, cfg, keep):
+    """_block_forward with the four linear layers on the fp8 MFMA path (BASELINE.json configs[3]): the LayerNorms emit the
+    e4m3 operand of the GEMM that follows them, the attention output and the MLP activation are quantised per token by
+    clipa_quantize_rows; everything between the GEMMs (residual stream, attention, softmax statistics, kept tensors) is
+    bf16 exactly as in the bf16 engine, and the weight gradients stay bf16 GEMMs of bf16 tensors."""
+    B, L, H, causal, act = cfg["B"], cfg["L"], cfg["H"], cfg["causal"], cfg["act"]
+    full = bool(keep) and keep not in ("light", "medium")
+    h1, q1, s1 = ops.layernorm_fwd_q8(x, P["ln1_w"], P["ln1_b"], cfg["eps"], want_bf16=full)
+    qkv = _lin8(q1, s1, P, "in")
+    del q1, s1
+    if keep:
+        a, stats = ops.attention_fwd(qkv, B, L, H, causal, want_stats=True)
+    else:
+        a, stats = ops.attention_fwd(qkv, B, L, H, causal), None
+    qa, sa = ops.quantize_rows(a)
+    x1 = _lin8(qa, sa, P, "out", epi=ops.EPI_ADD, aux=x)
+    del qa, sa
+    h2, q2, s2 = ops.layernorm_fwd_q8(x1, P["ln2_w"], P["ln2_b"], cfg["eps"], want_bf16=full)
+    if keep and keep != "medium":
+        g, hpre = _lin8(q2, s2, P, "fc", epi=ops.EPI_ACT, act=act, want_pre=True)
+    else:
+        g, hpre = _lin8(q2, s2, P, "fc", epi=ops.EPI_ACT, act=act), None
+    del q2, s2
+    qg, sg = ops.quantize_rows(g)
+    y = _lin8(qg, sg, P, "proj", epi=ops.EPI_ADD, aux=x1)
+    del qg, sg
+    if keep in ("light", "medium"):
+        return y, (None, qkv, a, stats, x1, None, hpre, None)
+    if keep:
+        return y, (h1, qkv, a, stats, x1, h2, hpre, g)
+    return y, None
+
+
 def _block_backward(x, dy, box, P, cfg):
     """box: one-element list holding the intermediates tuple (popped so they can be freed early)."""
     B, L, H, causal, act = cfg["B"], cfg["L"], cfg["H"], cfg["causal"], cfg["act"]
     h1, qkv, a, stats, x1, h2, hpre, g = box.pop()
     dy = dy.contiguous()
-    if hpre is None:     # "medium" block: LN2 + c_fc again (one GEMM instead of four + attention)
+    fp8 = bool(cfg.get("fp8"))
+    if hpre is None and fp8:
+        h2, q2, s2 = ops.layernorm_fwd_q8(x1, P["ln2_w"], P["ln2_b"], cfg["eps"], want_bf16=True)
+        g, hpre = _lin8(q2, s2, P, "fc", epi=ops.EPI_ACT, act=act, want_pre=True)
+        del q2, s2
+    elif hpre is None:   # "medium" block: LN2 + c_fc again (one GEMM instead of four + attention)
         h2 = ops.layernorm_fwd(x1, P["ln2_w"], P["ln2_b"], cfg["eps"])
         g, hpre = ops.gemm_nt(h2, P["w_fc"], P["b_fc"], epi=ops.EPI_ACT, act=act, want_pre=True)
     elif g is None:      # "light" block: cheap HBM-bound re-materialisation instead of 4 GEMMs + attention
         g = ops.activation_fwd(hpre, act)
         h2 = ops.layernorm_fwd(x1, P["ln2_w"], P["ln2_b"], cfg["eps"])
     # y = x1 + c_proj(g)
-    dh = ops.gemm_nt(dy, P["wt_proj"], epi=ops.EPI_DACT, act=act, aux=hpre)     # [M,4D]
+    if fp8:
+        dh = _dlin8(dy, P, "proj", cfg, epi=ops.EPI_DACT, act=act, aux=hpre)
+    else:
+        dh = ops.gemm_nt(dy, P["wt_proj"], epi=ops.EPI_DACT, act=act, aux=hpre)     # [M,4D]
     d_w_proj, d_b_proj = ops.gemm_tn(dy, g, P["dt_w_proj"], want_colsum=True)
     del g, hpre
-    dh2 = ops.gemm_nt(dh, P["wt_fc"])                                           # [M,D]
+    dh2 = _dlin8(dh, P, "fc", cfg) if fp8 else ops.gemm_nt(dh, P["wt_fc"])       # [M,D]
     d_w_fc, d_b_fc = ops.gemm_tn(dh, h2, P["dt_w_fc"], want_colsum=True)
     del dh, h2
     dx1, d_ln2_w, d_ln2_b = ops.layernorm_bwd(x1, P["ln2_w"], dh2, dres=dy, eps=cfg["eps"])
     del dh2, x1
     # x1 = x + out_proj(a)
-    da = ops.gemm_nt(dx1, P["wt_out"])
+    da = _dlin8(dx1, P, "out", cfg) if fp8 else ops.gemm_nt(dx1, P["wt_out"])
     d_w_out, d_b_out = ops.gemm_tn(dx1, a, P["dt_w_out"], want_colsum=True)
     dqkv = ops.attention_bwd(qkv, a, da, stats, B, L, H, causal)
     del da, a, qkv, stats
-    dh1 = ops.gemm_nt(dqkv, P["wt_in"])
+    dh1 = _dlin8(dqkv, P, "in", cfg) if fp8 else ops.gemm_nt(dqkv, P["wt_in"])
     if h1 is None:
         h1 = ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"])
     d_w_in, d_b_in = ops.gemm_tn(dqkv, h1, P["dt_w_in"], want_colsum=True)
@@ -124,15 +181,20 @@ BLOCK_PARAM_ORDER = ("ln1_w", "ln1_b", "w_in", "b_in", "w_out", "b_out", "ln2_w"
                      "b_proj")
 
 
-def _block_operands(params, cache):
+def _block_operands(params, cache, fp8=False):
     ln1_w, ln1_b, w_in, b_in, w_out, b_out, ln2_w, ln2_b, w_fc, b_fc, w_proj, b_proj = params
-    return {
+    P = {
         "ln1_w": cache.f32(ln1_w), "ln1_b": cache.f32(ln1_b), "ln2_w": cache.f32(ln2_w), "ln2_b": cache.f32(ln2_b),
         "w_in": cache.w(w_in), "w_out": cache.w(w_out), "w_fc": cache.w(w_fc), "w_proj": cache.w(w_proj),
         "wt_in": cache.wt(w_in), "wt_out": cache.wt(w_out), "wt_fc": cache.wt(w_fc), "wt_proj": cache.wt(w_proj),
         "b_in": cache.f32(b_in), "b_out": cache.f32(b_out), "b_fc": cache.f32(b_fc), "b_proj": cache.f32(b_proj),
         "dt_w_in": w_in.dtype, "dt_w_out": w_out.dtype, "dt_w_fc": w_fc.dtype, "dt_w_proj": w_proj.dtype,
     }
+    if fp8:   # e4m3 copies, one scale per output channel of the GEMM they feed (rows of W forward, rows of W^T backward)
+        for name, w in (("in", w_in), ("out", w_out), ("fc", w_fc), ("proj", w_proj)):
+            P["w8_" + name] = cache.custom(w, "w8", lambda t, w=w: ops.quantize_rows(cache.w(w)))
+            P["wt8_" + name] = cache.custom(w, "wt8", lambda t, w=w: ops.quantize_rows(cache.wt(w)))
+    return P
 
 
 class ResBlockFn(torch.autograd.Function):
@@ -140,7 +202,7 @@ class ResBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, cfg, cache, *params):
-        P = _block_operands(params, cache)
+        P = _block_operands(params, cache, bool(cfg.get("fp8")))
         needs_grad = any(ctx.needs_input_grad)
         keep = False
         if needs_grad:
@@ -156,7 +218,7 @@ class ResBlockFn(torch.autograd.Function):
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         cfg, params = ctx.cfg, ctx.params
-        P = _block_operands(params, ctx.cache)
+        P = _block_operands(params, ctx.cache, bool(cfg.get("fp8")))
         box = [ctx.inter]
         ctx.inter = None
         if box[0] is None:

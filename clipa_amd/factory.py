@@ -19,7 +19,7 @@ from .model import (CLIP, OPENAI_DATASET_MEAN, OPENAI_DATASET_STD, convert_weigh
 
 def get_cast_dtype(precision: str):
     """open_clip/model.py:78-86."""
-    if precision == 'bf16':
+    if precision in ('bf16', 'fp8'):
         return torch.bfloat16
     if precision == 'fp16':
         raise NotImplementedError("clipa_amd: fp16 is not an MI355X engine mode (bf16 MFMA path only)")
@@ -87,8 +87,13 @@ def create_model(
     elif require_pretrained:
         raise RuntimeError(f'Pretrained weights were required for (model: {model_name}) but not loaded.')
     model.to(device=device)
-    if precision in ("fp16", "bf16"):
-        convert_weights_to_lp(model, dtype=torch.bfloat16 if precision == 'bf16' else torch.float16)
+    if precision in ("fp16", "bf16", "fp8"):
+        convert_weights_to_lp(model, dtype=torch.float16 if precision == 'fp16' else torch.bfloat16)
+    if precision == "fp8":
+        # MI355X engine mode without a reference counterpart (training/params.py:195-200 stops at bf16): bf16 master
+        # weights and activations, fp8 (OCP e4m3) operands for the block GEMMs.  See engine._block_forward_fp8.
+        model.visual.transformer.fp8 = True
+        model.transformer.fp8 = True
     model.visual.image_mean = model_cfg.get("vision_cfg", {}).get('mean', None) or OPENAI_DATASET_MEAN
     model.visual.image_std = model_cfg.get("vision_cfg", {}).get('std', None) or OPENAI_DATASET_STD
     if output_dict and hasattr(model, "output_dict"):

@@ -22,6 +22,9 @@ SIGNATURES = {
     "clipa_gemm_nt": (_I32, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I32, _I32, _I32, _P]),
     "clipa_gemm_tn_workspace": (_I64, [_I64, _I64, _I64, _c.POINTER(_I64)]),
     "clipa_gemm_tn": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I32, _P, _I64, _P]),
+    "clipa_quantize_rows": (_I32, [_P, _P, _P, _I64, _I64, _I64, _I64, _I32, _P]),
+    "clipa_gemm_nt_f8": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I32, _I32, _I32, _I32, _P]),
+    "clipa_layernorm_fwd_q8": (_I32, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P]),
     "clipa_layernorm_fwd": (_I32, [_P, _P, _P, _P, _I64, _I64, _F, _I32, _I32, _P]),
     "clipa_layernorm_bwd_workspace": (_I64, [_I64, _I64]),
     "clipa_layernorm_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _F, _I32, _I32, _P, _I64, _P]),

@@ -149,6 +149,10 @@ class Transformer(nn.Module):
         # ... and the next `medium_blocks` blocks keep the same set minus the MLP pre-activation (~10*D bytes per
         # token) and re-run only LN2 + c_fc in backward.
         self.medium_blocks = 0
+        # fp8 engine mode (create_model(precision="fp8"), BASELINE.json configs[3]): the four linear layers of every block run
+        # forward and input-gradient GEMMs on e4m3 operands (engine._block_forward_fp8); "e5m2" switches the gradient operand
+        self.fp8 = False
+        self.fp8_grad_format = "e4m3"
         self.resblocks = nn.ModuleList([_ResBlockParams(width, heads, mlp_ratio) for _ in range(layers)])
 
     def get_cast_dtype(self):
@@ -156,7 +160,8 @@ class Transformer(nn.Module):
 
     def run(self, x, B, L, causal, cache):
         base = {"B": B, "L": L, "H": self.heads, "causal": bool(causal), "act": self.act, "eps": 1e-5,
-                "recompute": bool(self.grad_checkpointing), "keep": "light"}
+                "recompute": bool(self.grad_checkpointing), "keep": "light", "fp8": bool(self.fp8),
+                "fp8_grad_fmt": ops.FMT_E5M2 if self.fp8_grad_format == "e5m2" else ops.FMT_E4M3}
         kept, medium = dict(base, keep_this=True), dict(base, keep_this=True, keep="medium")
         for i, blk in enumerate(self.resblocks):
             cfg = kept if i < self.keep_blocks else (medium if i < self.keep_blocks + self.medium_blocks else base)

@@ -120,6 +120,69 @@ def gemm_nt(a, b, bias=None, *, epi=EPI_NONE, act=ACT_GELU_ERF, aux=None, alpha=
     return (out, pre) if want_pre else out
 
 
+FMT_E4M3, FMT_E5M2 = 0, 1
+u8 = torch.uint8
+
+
+def quantize_rows(x, fmt=FMT_E4M3):
+    """Row-scaled fp8 operand of a bf16 matrix: -> (q uint8 [M,K] holding OCP e4m3 / e5m2 bytes, dq f32 [M]) with
+    x[r,:] ~ dq[r] * fp8(q[r,:])."""
+    _chk(x, bf16, "x", 2)
+    x, ld = _rowmajor(x)
+    M, K = x.shape
+    q = torch.empty((M, K), device=x.device, dtype=u8)
+    dq = torch.empty(M, device=x.device, dtype=f32)
+    with _Timed("quantize_rows", 0.0, 3.0 * M * K, f"{M},{K}"):
+        lib.call("clipa_quantize_rows", _p(x), _p(q), _p(dq), M, K, ld, K, int(fmt), _stream())
+    return q, dq
+
+
+def layernorm_fwd_q8(x, gamma, beta, eps=1e-5, want_bf16=False):
+    """LayerNorm of bf16 rows emitting the e4m3 operand of the next GEMM: -> (y bf16 | None, q uint8, dq f32 [rows])."""
+    _chk(x, bf16, "x")
+    _chk(gamma, f32, "gamma", 1)
+    _chk(beta, f32, "beta", 1)
+    x = x.contiguous()
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty(x.shape, device=x.device, dtype=bf16) if want_bf16 else None
+    q = torch.empty(x.shape, device=x.device, dtype=u8)
+    dq = torch.empty(rows, device=x.device, dtype=f32)
+    lib.call("clipa_layernorm_fwd_q8", _p(x), _p(gamma), _p(beta), _p(y), _p(q), _p(dq), rows, D, float(eps), _stream())
+    return y, q, dq
+
+
+def gemm_nt_f8(a8, sa, b8, sb, bias=None, *, epi=EPI_NONE, act=ACT_GELU_ERF, aux=None, alpha=1.0, want_pre=False,
+               fmt_a=FMT_E4M3, fmt_b=FMT_E4M3):
+    """C[M,N] bf16 = epi(alpha * sa[m] * sb[n] * a8[M,K] @ b8[N,K]^T + bias); a8, b8 uint8 tensors of fp8 bytes."""
+    _chk(a8, u8, "a8", 2)
+    _chk(b8, u8, "b8", 2)
+    a8, lda = _rowmajor(a8)
+    b8, ldb = _rowmajor(b8)
+    M, K = a8.shape
+    N, Kb = b8.shape
+    if K != Kb:
+        raise RuntimeError(f"gemm_nt_f8: K mismatch {K} vs {Kb}")
+    for name, t, n in (("sa", sa, M), ("sb", sb, N)):
+        if t is not None:
+            _chk(t, f32, name, 1)
+            if t.numel() != n or not t.is_contiguous():
+                raise RuntimeError(f"gemm_nt_f8: {name} must be a contiguous f32 vector of {n} elements")
+    if bias is not None:
+        _chk(bias, f32, "bias", 1)
+    out = torch.empty((M, N), device=a8.device, dtype=bf16)
+    pre = torch.empty((M, N), device=a8.device, dtype=bf16) if want_pre else None
+    ldaux = 0
+    if aux is not None:
+        _chk(aux, bf16, "aux", 2)
+        aux, ldaux = _rowmajor(aux)
+    nbytes = 1.0 * (M * K + N * K) + 2.0 * M * N * (1 + (aux is not None) + bool(want_pre))
+    with _Timed("gemm_nt_f8", 2.0 * M * N * K, nbytes, f"{M},{N},{K},epi{epi}{'+pre' if want_pre else ''}"):
+        lib.call("clipa_gemm_nt_f8", _p(a8), _p(b8), _p(sa), _p(sb), _p(out), _p(pre), _p(bias), _p(aux), M, N, K, lda, ldb,
+                 N, ldaux, float(alpha), epi, act, int(fmt_a), int(fmt_b), _stream())
+    return (out, pre) if want_pre else out
+
+
 def gemm_tn(p, q, out_dtype=f32, want_colsum=False):
     """out[R,C] = p[M,R]^T @ q[M,C]; p, q bf16.  want_colsum: also return sum_m p[m,:] (f32 [R])."""
     _chk(p, bf16, "p", 2)

@@ -61,6 +61,24 @@ int64_t clipa_gemm_tn_workspace(int64_t M, int64_t R, int64_t C, int64_t* nslice
 int clipa_gemm_tn(const void* P, const void* Q, void* out, float* colsum_out, int64_t M, int64_t R, int64_t C,
                   int64_t ldp, int64_t ldq, int out_bf16, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* fp8 path (BASELINE.json configs[3]: "fp8 MFMA weights/activations"; the reference's precision menu,
+ * training/params.py:195-200, stops at bf16, so these have no reference counterpart - same call sites as clipa_gemm_nt:
+ * the linear layers of a residual block, transformer.py:209,217-219,234, forward and input gradient).
+ * clipa_quantize_rows: q[r,:] = fp8(x[r,:] * FMAX / max|x[r,:]|) (x bf16, q bytes; fmt 0 = OCP e4m3, FMAX 448; 1 = e5m2,
+ * FMAX 57344), dq[r] = max|x[r,:]| / FMAX (1 for an all-zero row).  K % 8 == 0, K <= 8192.
+ * clipa_gemm_nt_f8: C = epi(alpha * scale_a[m] * scale_b[n] * A8 . B8^T + bias[n]) on v_mfma_f32_16x16x128_f8f6f4, fp32
+ * accumulation, bf16 C / C2 / aux and the epilogues of clipa_gemm_nt; scale_a [M], scale_b [N] may be NULL (= 1).
+ * K, lda, ldb % 16 == 0 (bytes); N, ldc, ldaux % 8 == 0.
+ * clipa_layernorm_fwd_q8: LayerNorm of bf16 rows emitting the e4m3 operand of the next GEMM (q, dq as quantize_rows of
+ * the bf16-rounded output) and, when y != NULL, the bf16 output itself. */
+int clipa_quantize_rows(const void* x, void* q, float* dq, int64_t rows, int64_t K, int64_t ldx, int64_t ldq, int fmt,
+                        void* stream);
+int clipa_gemm_nt_f8(const void* A8, const void* B8, const float* scale_a, const float* scale_b, void* C, void* C2,
+                     const float* bias, const void* aux, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                     int64_t ldc, int64_t ldaux, float alpha, int epi, int act, int fmt_a, int fmt_b, void* stream);
+int clipa_layernorm_fwd_q8(const void* x, const float* gamma, const float* beta, void* y, void* q, float* dq,
+                           int64_t rows, int64_t D, float eps, void* stream);
+
 /* F.layer_norm over the last dim, eps inside sqrt, affine (transformer.py:19-34). x/dx share a dtype
  * (x_f32), y/dy share a dtype (y_f32). bwd: dx = LN'(dy) [+ dres]; dgamma, dbeta f32 [D]. */
 int clipa_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, int64_t rows,

@@ -43,6 +43,33 @@ def gemm_nt(a, b, bias=None, *, epi=EPI_NONE, act=0, aux=None, alpha=1.0, out_f3
     return (v, pre) if want_pre else v
 
 
+FMT_E4M3, FMT_E5M2 = 0, 1
+u8 = torch.uint8
+_F8 = {0: (torch.float8_e4m3fn, 448.0), 1: (torch.float8_e5m2, 57344.0)}
+
+
+def quantize_rows(x, fmt=FMT_E4M3):
+    dt, fmax = _F8[fmt]
+    xf = x.float()
+    amax = xf.abs().amax(dim=1)
+    s = torch.where(amax > 0, fmax / amax, torch.ones_like(amax))
+    dq = torch.where(amax > 0, amax / fmax, torch.ones_like(amax))
+    return (xf * s[:, None]).to(dt).view(u8), dq
+
+
+def layernorm_fwd_q8(x, gamma, beta, eps=1e-5, want_bf16=False):
+    y = layernorm_fwd(x, gamma, beta, eps)
+    q, dq = quantize_rows(y.reshape(-1, y.shape[-1]))
+    return (y if want_bf16 else None), q.reshape(y.shape), dq
+
+
+def gemm_nt_f8(a8, sa, b8, sb, bias=None, *, epi=EPI_NONE, act=0, aux=None, alpha=1.0, want_pre=False, fmt_a=FMT_E4M3,
+               fmt_b=FMT_E4M3):
+    a = a8.view(_F8[fmt_a][0]).float() * (sa[:, None] if sa is not None else 1.0)
+    b = b8.view(_F8[fmt_b][0]).float() * (sb[:, None] if sb is not None else 1.0)
+    return gemm_nt(a, b, bias, epi=epi, act=act, aux=aux, alpha=alpha, want_pre=want_pre)
+
+
 def gemm_tn(p, q, out_dtype=f32, want_colsum=False):
     out = (p.float().T @ q.float()).to(out_dtype)
     return (out, p.float().sum(0)) if want_colsum else out

@@ -23,11 +23,14 @@ def _swap_ops(monkeypatch):
         monkeypatch.setattr(mod, "ops", cpu_ops)
 
 
-def _run(g, recompute=True, precision="fp32", tiers=None):
+def _run(g, recompute=True, precision="fp32", tiers=None, grad_fmt="e4m3"):
     m = clipa_amd.CLIP(**g.cfg, output_dict=True)
     m.load_state_dict(g.sd, strict=True)
-    if precision == "bf16":
+    if precision in ("bf16", "fp8"):
         clipa_amd.convert_weights_to_lp(m, torch.bfloat16)
+    if precision == "fp8":
+        for t in (m.visual.transformer, m.transformer):
+            t.fp8, t.fp8_grad_format = True, grad_fmt
     m.set_grad_checkpointing(recompute)
     if tiers:
         for t in (m.visual.transformer, m.transformer):
@@ -83,6 +86,33 @@ def test_bf16_precision_mode_and_frozen_tower(golden):
     clipa_amd.ClipLoss()(**out).backward()
     assert m2.visual.proj.grad is not None and m2.visual.conv1.weight.grad is None
     assert m2.visual.transformer.resblocks[0].mlp.c_fc.weight.grad is None
+
+
+def test_fp8_orchestration(golden):
+    """precision="fp8" host wiring on the CPU stand-ins (torch float8 casts = the same OCP encodings and row scales as the
+    HIP quantiser): quantised operand forms (W rows forward, W^T rows backward), scale vectors, keep tiers.  Tolerance of
+    the fp8 recipe vs the fp32 reference at toy dimensions: features 6e-2, loss 4 %, gradient cosine >= 0.95."""
+    g = golden
+    m, out, loss = _run(g, precision="fp8")
+    assert (out["image_features"].float() - g.t("image_features")).abs().max() < 6e-2
+    assert (out["text_features"].float() - g.t("text_features")).abs().max() < 6e-2
+    assert abs(float(loss) - float(g.t("loss"))) < 4e-2 * float(g.t("loss"))
+    mb, _, _ = _run(g, precision="bf16")
+    ref = {k: p.grad for k, p in mb.named_parameters() if p.grad is not None}
+    for k, p in m.named_parameters():
+        if p.grad is None or p.grad.numel() == 1 or float(ref[k].float().norm()) < 1e-7:
+            continue
+        a, b = p.grad.double().reshape(-1), ref[k].double().reshape(-1)
+        assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.95, k
+    # recompute == stored == keep tiers, bit for bit (scales are functions of the data)
+    ma, _, la = _run(g, precision="fp8", recompute=False)
+    mc, _, lc = _run(g, precision="fp8", recompute=True, tiers=(1, 1))
+    assert float(loss) == float(la) == float(lc)
+    for (k, p), (_, q), (_, r) in zip(m.named_parameters(), ma.named_parameters(), mc.named_parameters()):
+        if p.grad is not None:
+            assert torch.equal(p.grad, q.grad) and torch.equal(p.grad, r.grad), k
+    me, _, le = _run(g, precision="fp8", grad_fmt="e5m2")
+    assert abs(float(le) - float(g.t("loss"))) < 4e-2 * float(g.t("loss"))
 
 
 def test_optimizer_step_refreshes_weight_cache_and_reduces_loss():

@@ -1,5 +1,6 @@
 """Run ONE kernel shape repeatedly (for rocprofv3 --pmc / --kernel-trace passes).
     python tools/gemm_probe.py nt M N K [epi] [iters]     epi in {none,bias,gelu,res}
+    python tools/gemm_probe.py f8 M N K [epi] [iters]     the fp8 GEMM on pre-quantised operands, same epilogues
     python tools/gemm_probe.py tn M R C
     python tools/gemm_probe.py attn_fwd|attn_bwd B H L causal
 """
@@ -30,6 +31,20 @@ if kind == "nt":
             ops.gemm_nt(a, w, bias, epi=ops.EPI_ADD, aux=res)
         else:
             ops.gemm_nt(a, w, bias if extra == "bias" else None)
+elif kind == "f8":
+    a = torch.randn(a1, a3, device=dev).to(bf16)
+    w = (torch.randn(a2, a3, device=dev) * 0.05).to(bf16)
+    bias = torch.randn(a2, device=dev)
+    res = torch.randn(a1, a2, device=dev).to(bf16) if extra == "res" else None
+    qa, sa = ops.quantize_rows(a)
+    qw, sw = ops.quantize_rows(w)
+    for _ in range(iters):
+        if extra == "gelu":
+            ops.gemm_nt_f8(qa, sa, qw, sw, bias, epi=ops.EPI_ACT, want_pre=True)
+        elif extra == "res":
+            ops.gemm_nt_f8(qa, sa, qw, sw, bias, epi=ops.EPI_ADD, aux=res)
+        else:
+            ops.gemm_nt_f8(qa, sa, qw, sw, bias if extra == "bias" else None)
 elif kind == "tn":
     p = torch.randn(a1, a2, device=dev).to(bf16)
     q = torch.randn(a1, a3, device=dev).to(bf16)
