@@ -128,6 +128,14 @@ def main():
                     help="share of the free HBM 'auto' may spend (default 0.93 single process, 0.86 with several ranks: no OOM back-off there)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shapes", action="store_true", help="also report time and TF/s per GEMM / attention shape (stderr)")
+    ap.add_argument("--optimizer", default="adamw", choices=["adamw", "sharded"],
+                    help="adamw = the reference's arrangement (DDP gradient all-reduce + a full fused AdamW per rank); sharded = "
+                         "clipa_amd.zero.ShardedAdamW (gradient reduce-scatter, optimizer state / W, parameter all-gather; no DDP wrapper)")
+    ap.add_argument("--exchange", default="reduce_scatter", choices=["reduce_scatter", "all_to_all"],
+                    help="--optimizer sharded: RCCL reduce-scatter, or one-hop all-to-all over the xGMI mesh + local sum")
+    ap.add_argument("--h2d-steps", type=int, default=2,
+                    help="extra steps (after the timed region, not part of `value`) whose batches come from pinned host memory "
+                         "through the device input pipeline: reported as `h2d_inclusive` (0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=8, help="pairs per CPU-baseline step")
     ap.add_argument("--cpu-timeout", type=int, default=240)
     args = ap.parse_args()
@@ -166,13 +174,18 @@ def main():
     model.set_grad_checkpointing(True)                         # every reference GPU script passes --grad-checkpointing
     named = list(model.named_parameters())
     exclude = lambda n, p: p.ndim < 2 or "bn" in n or "ln" in n or "bias" in n or "logit_scale" in n   # main.py:311-316
-    opt = AdamW([{"params": [p for n, p in named if exclude(n, p) and p.requires_grad], "weight_decay": 0.},
-                 {"params": [p for n, p in named if not exclude(n, p) and p.requires_grad], "weight_decay": 0.2}],
-                lr=5e-4, betas=(0.9, 0.95), eps=1e-6,
-                clamp=(model.logit_scale, 0.0, math.log(100)))      # train.py:285-286, fused into the update kernel
+    groups = [{"params": [p for n, p in named if exclude(n, p) and p.requires_grad], "weight_decay": 0.},
+              {"params": [p for n, p in named if not exclude(n, p) and p.requires_grad], "weight_decay": 0.2}]
     step_model = model
-    if dist_on:
-        step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], static_graph=True)
+    if args.optimizer == "sharded":
+        from clipa_amd.zero import ShardedAdamW
+        opt = ShardedAdamW(groups, lr=5e-4, betas=(0.9, 0.95), eps=1e-6, clamp=(model.logit_scale, 0.0, math.log(100)),
+                           exchange=args.exchange, force_collectives=dist_on)
+    else:
+        opt = AdamW(groups, lr=5e-4, betas=(0.9, 0.95), eps=1e-6,
+                    clamp=(model.logit_scale, 0.0, math.log(100)))      # train.py:285-286, fused into the update kernel
+        if dist_on:
+            step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], static_graph=True)
     loss_fn = clipa_amd.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True, rank=rank, world_size=world)
 
     B = args.batch
@@ -180,8 +193,8 @@ def main():
     # uint8 NHWC (channels_last) images + int64 token ids, resident in HBM before the timed region
     images, texts = synthetic_batch(B, args.image_size, args.ctx, cfg["text_cfg"]["vocab_size"], seed=1234 + rank, device=dev)
 
-    def step():
-        opt.zero_grad(set_to_none=True)
+    def step(images=images, texts=texts):
+        opt.zero_grad(set_to_none=True)                        # (the sharded optimizer zeroes its flat buffers instead)
         out = step_model(images, texts)
         loss = loss_fn(**out, output_dict=True)["contrastive_loss"]
         loss.backward()
@@ -264,6 +277,43 @@ def main():
         print(f"bench.py: non-finite loss {last_loss}", file=sys.stderr)
         sys.exit(3)
 
+    # PCIe-inclusive rate (the reference's batch_time includes the H2D copy, train.py:187-189): the same step
+    # fed from pinned host memory with staged uint8 NHWC images through DevicePrefetcher (copy stream, double buffered) +
+    # the on-device RandomResizedCrop / Grayscale of the reference GPU recipe (scripts/exp/gpu/vit_l16/i37_t8_pretrain.sh:13).
+    # Never part of `value`.
+    h2d = None
+    if args.h2d_steps > 0:
+        try:
+            from clipa_amd.data import DeviceAugment, DevicePrefetcher
+            stage = (args.image_size * 8 // 7 + 15) // 16 * 16                  # 224 -> 256, 84 -> 96
+            gh = torch.Generator().manual_seed(99 + rank)
+            base = torch.randint(0, 256, (64, stage, stage, 3), generator=gh, dtype=torch.uint8)
+            pool = [base.roll(k, 0).repeat((B + 63) // 64, 1, 1, 1)[:B].contiguous().pin_memory() for k in range(2)]
+            texts_host = texts.cpu().pin_memory()
+            n_h2d = args.h2d_steps
+            loader = ((pool[i % 2], texts_host) for i in range(n_h2d + 1))
+            aug = DeviceAugment(args.image_size, scale=(0.4, 1.0), gray_scale_prob=0.2, seed=7 + rank)
+            feed = iter(DevicePrefetcher(loader, dev, transform=aug, depth=2))
+            step(*next(feed))                                                    # warm-up of the pipeline itself
+            fence()
+            th = time.perf_counter()
+            for _ in range(n_h2d):
+                loss_h = step(*next(feed))
+            fence()
+            eh = time.perf_counter() - th
+            if dist_on:
+                tm = torch.tensor([eh], device=dev, dtype=torch.float64)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                eh = float(tm)
+            ops.check_token_ids(wait=True)
+            h2d = {"value": round(B * world * n_h2d / eh, 2), "unit": "pairs/s", "ms_per_step": round(1e3 * eh / n_h2d, 2),
+                   "steps": n_h2d, "loss": round(float(loss_h), 4),
+                   "input": f"uint8 NHWC {stage}x{stage} staged images in pinned host memory -> DevicePrefetcher (depth 2, copy "
+                            f"stream) -> on-device RandomResizedCrop(scale 0.4-1, bicubic) + Grayscale(p=0.2) -> {args.image_size} px"}
+            del pool, feed
+        except (RuntimeError, torch.OutOfMemoryError) as e:                      # the headline line must survive
+            h2d = {"value": None, "error": str(e)[:200]}
+
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         pairs_s = B * world * args.steps / elapsed
@@ -289,7 +339,7 @@ def main():
             "dtype": "fp8" if args.precision == "fp8" else "bf16", "data": "synthetic",
             "config": {"workload": f"{args.model}@{args.image_size} + text-{args.ctx}, local batch {B}, "
                                    f"global batch {B * world}, InfoNCE local_loss+gather_with_grad, AdamW, "
-                                   f"block recompute except {int(keep_v)}+{int(keep_t)} light-kept and {int(med_v)}+{int(med_t)} medium-kept (image+text) blocks", "precision": args.precision, "parallelism": f"dp{world}",
+                                   f"block recompute except {int(keep_v)}+{int(keep_t)} light-kept and {int(med_v)}+{int(med_t)} medium-kept (image+text) blocks", "precision": args.precision, "parallelism": f"dp{world}" + ("" if args.optimizer == "adamw" else f" zero1/{args.exchange}"),
                        "global_batch": B * world, "train_gflop_per_pair": round(gf, 2)},
             "model_flops_util": round(pairs_s / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4),
             "loss": round(last_loss, 4), "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
@@ -300,6 +350,7 @@ def main():
                          "traffic": traffic, "algorithmic_bytes_per_launch": round(nt.get("bytes", 0.0) / max(nt["launches"], 1)),
                          "launches": nt["launches"],
                          "avg_launch_ms": round(nt["ms"] / max(nt["launches"], 1), 4)},
+            "h2d_inclusive": h2d,
             "kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 2),
                             "tflops": round(v["work"] / max(v["ms"], 1e-9) / 1e9, 1)} for k, v in prof.items() if "|" not in k},
         }

@@ -10,4 +10,7 @@ from .loss import ClipLoss
 from .model import (CLIP, CLIPTextCfg, CLIPVisionCfg, OPENAI_DATASET_MEAN, OPENAI_DATASET_STD, convert_weights_to_lp,
                     get_2d_sincos_pos_embed, resize_pos_embed, resize_text_pos_embed)
 
-__version__ = "0.1.0"
+from .data import DeviceAugment, DevicePrefetcher
+from .zero import ShardedAdamW
+
+__version__ = "0.2.0"

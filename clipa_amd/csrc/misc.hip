@@ -81,9 +81,10 @@ __global__ void assemble_tokens_kernel(const unsigned short* __restrict__ patch,
 
 // dpos[l,:] = sum_b dtok[b,l,:]; dcls = dpos[0] (before pos add, the cls row only sees cls);
 // dpatch[b*g2+i,:] = dtok[b,1+i,:]
+// Batch sums are two-level and ORDERED (per-chunk partials in a workspace, then a fixed-order reduce): no float atomics,
+// so dcls / dpos are bit-reproducible from run to run (recompute == stored tests compare gradients bit for bit).
 __global__ void assemble_tokens_bwd_kernel(const unsigned short* __restrict__ dtok, unsigned short* __restrict__ dpatch,
-                                           float* __restrict__ dcls, float* __restrict__ dpos, long B, int L, int D,
-                                           int bchunk) {
+                                           float* __restrict__ part, long B, int L, int D, int bchunk) {
   const int dc = D / 8;
   const int c = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) % dc);
   const int l = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) / dc);
@@ -99,11 +100,21 @@ __global__ void assemble_tokens_bwd_kernel(const unsigned short* __restrict__ dt
     for (int i = 0; i < 8; ++i) acc[i] += v[i];
     if (l > 0 && dpatch) *(u32x4*)(dpatch + ((size_t)b * (L - 1) + (l - 1)) * D + c * 8) = raw;
   }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    if (dpos) atomicAdd(dpos + (size_t)l * D + c * 8 + i, acc[i]);
-    if (l == 0 && dcls) atomicAdd(dcls + c * 8 + i, acc[i]);
-  }
+  float* o = part + ((size_t)blockIdx.y * L + l) * D + c * 8;
+  *(float4*)o = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  *(float4*)(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+}
+
+// dpos[l][d] = sum over chunks (in chunk order) of part[chunk][l][d]; dcls = row 0 of the same sums
+__global__ void assemble_tokens_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dcls,
+                                                  float* __restrict__ dpos, int L, int D, int nchunk) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = dpos ? (long)L * D : (long)D;       // without dpos only the cls row is needed
+  if (i >= n) return;
+  float a = 0.f;
+  for (int ch = 0; ch < nchunk; ++ch) a += part[(size_t)ch * L * D + i];
+  if (dpos) dpos[i] = a;
+  if (dcls && i < D) dcls[i] = a;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -401,22 +412,43 @@ extern "C" int clipa_assemble_tokens(const void* patch, const float* cls, const 
   return clipa_check_launch("assemble_tokens");
 }
 
+namespace {
+void assemble_bwd_chunks(long B, long L, long D, int* nchunk, int* bchunk) {
+  const long threads = L * (D / 8);
+  long nc = (4096L * 256 + threads - 1) / threads;
+  if (nc > B) nc = B;
+  if (nc < 1) nc = 1;
+  const long bc = (B + nc - 1) / nc;
+  *bchunk = (int)bc;
+  *nchunk = (int)((B + bc - 1) / bc);
+}
+}  // namespace
+
+extern "C" int64_t clipa_assemble_tokens_bwd_workspace(int64_t B, int64_t L, int64_t D) {
+  if (B <= 0) return 0;
+  int nchunk, bchunk;
+  assemble_bwd_chunks(B, L, D, &nchunk, &bchunk);
+  return (int64_t)nchunk * L * D * (int64_t)sizeof(float);
+}
+
 extern "C" int clipa_assemble_tokens_bwd(const void* dtokens, void* dpatch, float* dcls, float* dpos,
-                                         int64_t B, int64_t L, int64_t D, void* stream) {
+                                         int64_t B, int64_t L, int64_t D, void* workspace, int64_t workspace_bytes,
+                                         void* stream) {
   if (D % 8 != 0) { clipa_set_error("assemble_tokens_bwd: D%%8 != 0"); return CLIPA_ERR_ARG; }
   if (B <= 0) return CLIPA_OK;
+  if (!workspace || workspace_bytes < clipa_assemble_tokens_bwd_workspace(B, L, D)) { clipa_set_error("assemble_tokens_bwd: workspace too small"); return CLIPA_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
-  if (dcls) (void)hipMemsetAsync(dcls, 0, D * sizeof(float), st);
-  if (dpos) (void)hipMemsetAsync(dpos, 0, L * D * sizeof(float), st);
+  int nchunk, bchunk;
+  assemble_bwd_chunks(B, L, D, &nchunk, &bchunk);
   const long threads = L * (D / 8);
-  int nchunk = (int)((4096 * 256 + threads - 1) / threads);
-  if (nchunk > B) nchunk = (int)B;
-  if (nchunk < 1) nchunk = 1;
-  const int bchunk = (int)((B + nchunk - 1) / nchunk);
-  nchunk = (int)((B + bchunk - 1) / bchunk);
   hipLaunchKernelGGL(assemble_tokens_bwd_kernel, dim3((unsigned)((threads + 255) / 256), (unsigned)nchunk), dim3(256), 0, st,
-                     (const unsigned short*)dtokens, (unsigned short*)dpatch, dcls, dpos, (long)B, (int)L, (int)D, bchunk);
-  return clipa_check_launch("assemble_tokens_bwd");
+                     (const unsigned short*)dtokens, (unsigned short*)dpatch, (float*)workspace, (long)B, (int)L, (int)D, bchunk);
+  if (int rc = clipa_check_launch("assemble_tokens_bwd")) return rc;
+  if (!dcls && !dpos) return CLIPA_OK;
+  const long n = dpos ? L * D : D;
+  hipLaunchKernelGGL(assemble_tokens_bwd_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
+                     dcls, dpos, (int)L, (int)D, nchunk);
+  return clipa_check_launch("assemble_tokens_bwd_reduce");
 }
 
 extern "C" int clipa_embed_tokens(const int64_t* ids, const void* table, int table_bf16, const float* pos,
@@ -431,7 +463,8 @@ extern "C" int clipa_embed_tokens(const int64_t* ids, const void* table, int tab
 }
 
 extern "C" int clipa_embed_tokens_bwd(const int64_t* ids, const void* dx, float* dtable, float* dpos,
-                                      int64_t B, int64_t T, int64_t D, int64_t vocab, int32_t* oob_count, void* stream) {
+                                      int64_t B, int64_t T, int64_t D, int64_t vocab, int32_t* oob_count, void* workspace,
+                                      int64_t workspace_bytes, void* stream) {
   if (D % 8 != 0) { clipa_set_error("embed_tokens_bwd: D%%8 != 0"); return CLIPA_ERR_ARG; }
   if (B <= 0) return CLIPA_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -440,7 +473,7 @@ extern "C" int clipa_embed_tokens_bwd(const int64_t* ids, const void* dx, float*
     hipLaunchKernelGGL(embed_tokens_bwd_kernel, dim3(grid_for(B * T * (D / 8))), dim3(256), 0, st, (const long*)ids, (const unsigned short*)dx, dtable, (long)B, (int)T, (int)D, (int)vocab, oob_count);
     if (int rc = clipa_check_launch("embed_tokens_bwd")) return rc;
   }
-  if (dpos) return clipa_assemble_tokens_bwd(dx, nullptr, nullptr, dpos, B, T, D, stream);
+  if (dpos) return clipa_assemble_tokens_bwd(dx, nullptr, nullptr, dpos, B, T, D, workspace, workspace_bytes, stream);
   return CLIPA_OK;
 }
 

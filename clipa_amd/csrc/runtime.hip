@@ -207,3 +207,48 @@ extern "C" int clipa_adamw(void* param, const void* grad, float* exp_avg, float*
 #undef LAUNCH
   return clipa_check_launch("adamw");
 }
+
+// out[i] = scale * sum_{w < W} in[w * n + i]: the local half of a one-hop gradient reduce-scatter (every rank sends shard j
+// of its gradients straight to rank j - an all-to-all over the xGMI mesh - and sums the W pieces it received; replaces the
+// ring reduction inside DDP's bucket all-reduce, clipa_torch/training/main.py:292-299).  Pieces are summed in rank order in
+// fp32: the same result on every run.  HBM-bound, 16-byte accesses.
+namespace {
+template <bool IN_F32, bool OUT_F32>
+__global__ void reduce_shards_kernel(const void* __restrict__ in, void* __restrict__ out, long n, int W, float scale) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i >= n) return;
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int w = 0; w < W; ++w) {
+    float v[8];
+    if (IN_F32) {
+      const float4 x = *(const float4*)((const float*)in + (size_t)w * n + i), y = *(const float4*)((const float*)in + (size_t)w * n + i + 4);
+      v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+    } else {
+      unpack8(*(const u32x4*)((const unsigned short*)in + (size_t)w * n + i), v);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] += v[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] *= scale;
+  if (OUT_F32) {
+    *(float4*)((float*)out + i) = make_float4(a[0], a[1], a[2], a[3]);
+    *(float4*)((float*)out + i + 4) = make_float4(a[4], a[5], a[6], a[7]);
+  } else {
+    *(u32x4*)((unsigned short*)out + i) = pack8(a);
+  }
+}
+}  // namespace
+
+extern "C" int clipa_reduce_shards(const void* in, void* out, int64_t n, int W, int in_f32, int out_f32, float scale,
+                                   void* stream) {
+  if (n <= 0) return CLIPA_OK;
+  if (n % 8 != 0 || W <= 0) { clipa_set_error("reduce_shards: n must be a multiple of 8 and W > 0"); return CLIPA_ERR_ARG; }
+  const dim3 grid((unsigned)((n / 8 + 255) / 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (in_f32 && out_f32) hipLaunchKernelGGL((reduce_shards_kernel<true, true>), grid, block, 0, st, in, out, (long)n, W, scale);
+  else if (in_f32) hipLaunchKernelGGL((reduce_shards_kernel<true, false>), grid, block, 0, st, in, out, (long)n, W, scale);
+  else if (out_f32) hipLaunchKernelGGL((reduce_shards_kernel<false, true>), grid, block, 0, st, in, out, (long)n, W, scale);
+  else hipLaunchKernelGGL((reduce_shards_kernel<false, false>), grid, block, 0, st, in, out, (long)n, W, scale);
+  return clipa_check_launch("reduce_shards");
+}

@@ -28,3 +28,155 @@ def synthetic_batch(batch, image_size, ctx, vocab, seed, device="cpu", channels_
     txt[:, 1] = 1 + (torch.arange(batch, device=txt.device) % (vocab - 3))
     img = img.contiguous(memory_format=torch.channels_last) if channels_last else img.contiguous()
     return img, txt
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Device-side input pipeline.  The reference decodes, crops, resizes and colour-converts every image
+# on host CPU workers (open_clip/transform.py:152-168 inside the loaders of training/data.py:332-436 /
+# reader_tfds.py:322-350) and ships the finished uint8 tensor (`images.to(device, non_blocking=True)`,
+# training/train.py:187-189); it already moved the float conversion to the device because the hosts could not keep up at
+# ~9 k pairs/s.  Here the loader only has to deliver decoded uint8 NHWC images at a fixed staging resolution; the copy is
+# double-buffered through pinned memory on its own HIP stream and RandomResizedCrop / Grayscale run as HIP kernels
+# (clipa_amd/csrc/augment.hip, bit-exact with the Pillow code torchvision calls) while the previous step computes.
+import collections
+import math
+
+
+def random_resized_crop_params(height, width, scale=(0.9, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0), generator=None):
+    """torchvision.transforms.RandomResizedCrop.get_params (the box sampler behind open_clip/transform.py:153-157),
+    restated with an explicit torch.Generator: up to 10 attempts at (area fraction ~ U(scale), aspect ~ log-U(ratio)) that
+    fit the image, else the largest central crop inside the ratio bounds.  -> (top, left, h, w)."""
+    area = height * width
+    log_ratio = (math.log(ratio[0]), math.log(ratio[1]))
+    for _ in range(10):
+        target_area = area * torch.empty(1).uniform_(scale[0], scale[1], generator=generator).item()
+        aspect = math.exp(torch.empty(1).uniform_(log_ratio[0], log_ratio[1], generator=generator).item())
+        w = int(round(math.sqrt(target_area * aspect)))
+        h = int(round(math.sqrt(target_area / aspect)))
+        if 0 < w <= width and 0 < h <= height:
+            i = int(torch.randint(0, height - h + 1, (1,), generator=generator).item())
+            j = int(torch.randint(0, width - w + 1, (1,), generator=generator).item())
+            return i, j, h, w
+    in_ratio = float(width) / float(height)
+    if in_ratio < min(ratio):
+        w = width
+        h = int(round(w / min(ratio)))
+    elif in_ratio > max(ratio):
+        h = height
+        w = int(round(h * max(ratio)))
+    else:
+        w, h = width, height
+    return (height - h) // 2, (width - w) // 2, h, w
+
+
+def sample_crop_boxes(batch, height, width, scale=(0.9, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0), generator=None):
+    """The same distribution for a whole batch in a handful of tensor ops (a Python loop over 4096 samples would cost more
+    host time than the step it feeds): int32 [batch, 4] = (top, left, h, w) on the CPU."""
+    area = float(height * width)
+    u = torch.rand(batch, 10, generator=generator, dtype=torch.float64)
+    v = torch.rand(batch, 10, generator=generator, dtype=torch.float64)
+    target = area * (scale[0] + (scale[1] - scale[0]) * u)
+    aspect = torch.exp(math.log(ratio[0]) + (math.log(ratio[1]) - math.log(ratio[0])) * v)
+    w = torch.round(torch.sqrt(target * aspect)).long()
+    h = torch.round(torch.sqrt(target / aspect)).long()
+    ok = (w > 0) & (w <= width) & (h > 0) & (h <= height)
+    first = torch.where(ok.any(1), ok.float().argmax(1), torch.zeros(batch, dtype=torch.long))
+    idx = torch.arange(batch)
+    w, h = w[idx, first], h[idx, first]
+    fi, fj, fh, fw = random_resized_crop_params(height, width, (2.0, 2.0), ratio)     # scale 2 never fits: the fallback box
+    none = ~ok.any(1)
+    w = torch.where(none, torch.full_like(w, fw), w)
+    h = torch.where(none, torch.full_like(h, fh), h)
+    ri = torch.rand(batch, generator=generator, dtype=torch.float64)
+    rj = torch.rand(batch, generator=generator, dtype=torch.float64)
+    top = torch.minimum((ri * (height - h + 1).double()).long(), height - h)
+    left = torch.minimum((rj * (width - w + 1).double()).long(), width - w)
+    top = torch.where(none, torch.full_like(top, fi), top)
+    left = torch.where(none, torch.full_like(left, fj), left)
+    return torch.stack([top, left, h, w], 1).to(torch.int32).contiguous()
+
+
+class DeviceAugment:
+    """RandomResizedCrop(image_size, scale, ratio, BICUBIC) [+ gray_scale(p)] of open_clip/transform.py:152-168 on a staged
+    uint8 NHWC device batch.  Returns uint8 [B, 3, S, S] in channels_last memory - the model's input format.
+    (color_jitter is not covered: batches that need it must be jittered by the loader.)"""
+
+    def __init__(self, image_size, scale=(0.9, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0), gray_scale_prob=0.0, seed=0):
+        self.size, self.scale, self.ratio, self.gray_p = int(image_size), tuple(scale), tuple(ratio), float(gray_scale_prob or 0.0)
+        self.gen = torch.Generator(device="cpu").manual_seed(int(seed))
+
+    def __call__(self, staged):
+        from . import ops
+        B, Hs, Ws, _ = staged.shape
+        boxes = sample_crop_boxes(B, Hs, Ws, self.scale, self.ratio, self.gen)
+        gray = None
+        if self.gray_p > 0:
+            gray = (torch.rand(B, generator=self.gen) < self.gray_p).to(torch.uint8)
+        if staged.is_cuda:
+            boxes = boxes.pin_memory().to(staged.device, non_blocking=True)
+            gray = gray.pin_memory().to(staged.device, non_blocking=True) if gray is not None else None
+        out = ops.resized_crop_u8(staged, boxes, self.size, gray)
+        return out.permute(0, 3, 1, 2)
+
+
+class DevicePrefetcher:
+    """Iterate a host loader of (images uint8 [B,H,W,3] or [B,3,H,W], texts int64 [B,ctx]) batches `depth` batches ahead:
+    each batch is staged in a pinned buffer, copied on a dedicated HIP stream and (optionally) augmented there, so the H2D
+    copy of training/train.py:187-189 and the transform overlap the previous step instead of preceding this one."""
+
+    def __init__(self, loader, device, transform=None, depth=2):
+        self.loader, self.device, self.transform, self.depth = loader, torch.device(device), transform, max(1, int(depth))
+        self.cuda = self.device.type == "cuda"
+        self.stream = torch.cuda.Stream(self.device) if self.cuda else None
+        self._pins = [dict() for _ in range(self.depth)]      # slot -> {name: pinned tensor}
+        self._free = [None] * self.depth                       # slot -> event after which the pinned buffers may be rewritten
+
+    def _stage(self, slot, name, t):
+        t = torch.as_tensor(t)
+        if not self.cuda or t.is_pinned():
+            return t
+        buf = self._pins[slot].get(name)
+        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+            buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            self._pins[slot][name] = buf
+        buf.copy_(t)
+        return buf
+
+    def _submit(self, slot, batch):
+        images, texts = batch
+        if self._free[slot] is not None:
+            self._free[slot].synchronize()                     # the copy that last read this slot's pinned buffers is done
+        images, texts = self._stage(slot, "images", images), self._stage(slot, "texts", texts)
+        if not self.cuda:
+            return (self.transform(images) if self.transform else images), texts, None
+        with torch.cuda.stream(self.stream):
+            d_img = images.to(self.device, non_blocking=True)
+            d_txt = texts.to(self.device, non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record(self.stream)
+            self._free[slot] = copied
+            if self.transform is not None:
+                d_img = self.transform(d_img)
+            ready = torch.cuda.Event()
+            ready.record(self.stream)
+        return d_img, d_txt, ready
+
+    def __iter__(self):
+        queue = collections.deque()
+        slot = 0
+        for batch in self.loader:
+            queue.append(self._submit(slot, batch))
+            slot = (slot + 1) % self.depth
+            if len(queue) >= self.depth:
+                yield self._hand_over(queue.popleft())
+        while queue:
+            yield self._hand_over(queue.popleft())
+
+    def _hand_over(self, item):
+        d_img, d_txt, ready = item
+        if ready is not None:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ready)
+            d_img.record_stream(cur)
+            d_txt.record_stream(cur)
+        return d_img, d_txt

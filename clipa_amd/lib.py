@@ -31,10 +31,13 @@ SIGNATURES = {
     "clipa_attention_fwd": (_I32, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I32, _P]),
     "clipa_attention_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I32, _P]),
     "clipa_patchify": (_I32, [_P, _P, _I64, _I64, _I64, _I64, _I32, _I32, _I32, _c.POINTER(_F), _c.POINTER(_F), _P]),
+    "clipa_resized_crop_workspace": (_I64, [_I64, _I64, _I64]),
+    "clipa_resized_crop_u8": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _I64, _P, _P]),
     "clipa_assemble_tokens": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
-    "clipa_assemble_tokens_bwd": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
+    "clipa_assemble_tokens_bwd_workspace": (_I64, [_I64, _I64, _I64]),
+    "clipa_assemble_tokens_bwd": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _I64, _P]),
     "clipa_embed_tokens": (_I32, [_P, _P, _I32, _P, _P, _I64, _I64, _I64, _I64, _P, _P]),
-    "clipa_embed_tokens_bwd": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P]),
+    "clipa_embed_tokens_bwd": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P]),
     "clipa_argmax_tokens": (_I32, [_P, _P, _I64, _I64, _P]),
     "clipa_pool_fwd": (_I32, [_P, _P, _P, _I64, _I64, _I64, _I32, _P]),
     "clipa_pool_bwd": (_I32, [_P, _P, _P, _I64, _I64, _I64, _I32, _P]),
@@ -54,6 +57,7 @@ SIGNATURES = {
     "clipa_adamw_multi": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _F, _F, _F, _F, _F, _I64, _F, _P, _I32, _F, _F, _P]),
     "clipa_grad_sqnorm_multi": (_I32, [_P, _P, _I32, _I32, _P, _P]),
     "clipa_clip_coef": (_I32, [_P, _F, _P, _P, _P]),
+    "clipa_reduce_shards": (_I32, [_P, _P, _I64, _I32, _I32, _I32, _F, _P]),
 }
 
 _lib = None

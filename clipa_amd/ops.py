@@ -297,6 +297,33 @@ def patchify(img, P, Kp, mean=None, std=None):
     return out
 
 
+def resized_crop_u8(src, boxes, size, gray_flags=None):
+    """Device-side RandomResizedCrop (+ Grayscale of the flagged samples), bit-exact with Pillow's bicubic resize of the
+    cropped image: src uint8 [B,Hs,Ws,3] (NHWC), boxes int32 [B,4] = (top, left, height, width) -> uint8 [B,size,size,3].
+    Samples whose box leaves the image (or shrinks more than 11x) come back as zeros and raise at the next check."""
+    _chk(src, u8, "src", 4)
+    _chk(boxes, torch.int32, "boxes", 2)
+    if src.shape[3] != 3 or not src.is_contiguous():
+        raise RuntimeError(f"resized_crop_u8: src must be a contiguous uint8 [B,H,W,3] tensor, got {tuple(src.shape)}")
+    B, Hs, Ws, _ = src.shape
+    if tuple(boxes.shape) != (B, 4) or not boxes.is_contiguous():
+        raise RuntimeError(f"resized_crop_u8: boxes must be contiguous int32 [{B},4]")
+    if gray_flags is not None:
+        _chk(gray_flags, u8, "gray_flags", 1)
+        if gray_flags.numel() != B:
+            raise RuntimeError("resized_crop_u8: gray_flags must have one byte per sample")
+    check_token_ids()                                   # surfaces an earlier launch's rejected samples
+    out = torch.empty((B, size, size, 3), device=src.device, dtype=u8)
+    wsb = lib.query("clipa_resized_crop_workspace", B, Hs, size)
+    ws = torch.empty(wsb, device=src.device, dtype=u8)
+    err = _oob_counter(src.device)
+    with _Timed("resized_crop", 0.0, 3.0 * B * (Hs * Ws + Hs * size * 2 + size * size)):
+        lib.call("clipa_resized_crop_u8", _p(src), _p(boxes), _p(gray_flags), _p(out), B, Hs, Ws, size, _p(ws), wsb, _p(err),
+                 _stream())
+    _oob_submit(err, "resized_crop_u8", "samples rejected (crop box outside the image or a down-scale above 11x)")
+    return out
+
+
 def assemble_tokens(patch, cls, pos, B, L):
     D = patch.shape[1]
     tok = torch.empty((B * L, D), device=patch.device, dtype=bf16)
@@ -310,7 +337,9 @@ def assemble_tokens_bwd(dtok, B, L, need_pos=True):
     dpatch = torch.empty((B * (L - 1), D), device=dtok.device, dtype=bf16)
     dcls = torch.empty(D, device=dtok.device, dtype=f32)
     dpos = torch.empty((L, D), device=dtok.device, dtype=f32) if need_pos else None
-    lib.call("clipa_assemble_tokens_bwd", _p(dtok), _p(dpatch), _p(dcls), _p(dpos), B, L, D, _stream())
+    wsb = lib.query("clipa_assemble_tokens_bwd_workspace", B, L, D)
+    ws = torch.empty(max(wsb, 4) // 4, device=dtok.device, dtype=f32)
+    lib.call("clipa_assemble_tokens_bwd", _p(dtok), _p(dpatch), _p(dcls), _p(dpos), B, L, D, _p(ws), wsb, _stream())
     return dpatch, dcls, dpos
 
 
@@ -324,12 +353,12 @@ def _oob_counter(device):
     return torch.zeros(1, device=device, dtype=torch.int32)
 
 
-def _oob_submit(counter, what):
+def _oob_submit(counter, what, msg="token ids outside [0, vocab) (nn.Embedding would raise)"):
     host = torch.empty(1, dtype=torch.int32, pin_memory=True)
     host.copy_(counter, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
-    _OOB_PENDING.append((host, ev, what, counter))
+    _OOB_PENDING.append((host, ev, (what, msg), counter))
 
 
 def check_token_ids(wait=False):
@@ -341,7 +370,7 @@ def check_token_ids(wait=False):
         if ev.query():
             if int(host[0]) != 0:
                 _OOB_PENDING.clear()
-                raise RuntimeError(f"clipa_amd.ops.{what}: {int(host[0])} token ids outside [0, vocab) (nn.Embedding would raise)")
+                raise RuntimeError(f"clipa_amd.ops.{what[0]}: {int(host[0])} {what[1]}")
         else:
             keep.append((host, ev, what, counter))
     _OOB_PENDING[:] = keep
@@ -370,7 +399,9 @@ def embed_tokens_bwd(ids, dx, vocab, need_table=True, need_pos=True):
     dtable = torch.empty((vocab, D), device=dx.device, dtype=f32) if need_table else None
     dpos = torch.empty((T, D), device=dx.device, dtype=f32) if need_pos else None
     oob = _oob_counter(ids.device)
-    lib.call("clipa_embed_tokens_bwd", _p(ids), _p(dx), _p(dtable), _p(dpos), B, T, D, vocab, _p(oob), _stream())
+    wsb = lib.query("clipa_assemble_tokens_bwd_workspace", B, T, D) if need_pos else 0
+    ws = torch.empty(max(wsb, 4) // 4, device=dx.device, dtype=f32)
+    lib.call("clipa_embed_tokens_bwd", _p(ids), _p(dx), _p(dtable), _p(dpos), B, T, D, vocab, _p(oob), _p(ws), wsb, _stream())
     _oob_submit(oob, "embed_tokens_bwd")
     return dtable, dpos
 
@@ -541,21 +572,46 @@ def adamw_multi_(params, grads, exp_avgs, exp_avg_sqs, *, lr, beta1, beta2, eps,
              float(grad_scale), _p(grad_scale_dev), int(clamp_index), float(clamp[0]), float(clamp[1]), _stream())
 
 
-def grad_clip_coef(grads, max_norm):
-    """clip_grad_norm_ on the device: -> (total_norm, coef) f32 device scalars, coef = min(1, max_norm / (norm + 1e-6))."""
+def grad_sqnorm(grads, buf=None):
+    """buf[0] += sum of squares of the listed gradients (device f32 [3] = [sum of squares, norm, coef]; created zeroed)."""
     dev = grads[0].device
-    buf = torch.zeros(3, device=dev, dtype=f32)           # [sum of squares, norm, coef]
+    if buf is None:
+        buf = torch.zeros(3, device=dev, dtype=f32)
     for is32 in (True, False):
         sel = [g for g in grads if (g.dtype == f32) == is32]
         if not sel:
             continue
         for g in sel:
             if g.dtype not in (f32, bf16) or not g.is_contiguous() or not g.is_cuda:
-                raise RuntimeError("grad_clip_coef: gradients must be contiguous f32 / bf16 GPU tensors")
+                raise RuntimeError("grad_sqnorm: gradients must be contiguous f32 / bf16 GPU tensors")
         n = len(sel)
         arr = ctypes.c_void_p * n
         cnt = (ctypes.c_int64 * n)(*[g.numel() for g in sel])
         lib.call("clipa_grad_sqnorm_multi", arr(*[g.data_ptr() for g in sel]), cnt, n, int(is32), _p(buf), _stream())
+    return buf
+
+
+def clip_coef(buf, max_norm):
+    """buf[0] = sum of squares -> (total_norm, coef) device scalars (views of buf), coef = min(1, max_norm / (norm + 1e-6))."""
     lib.call("clipa_clip_coef", _p(buf), float(max_norm), ctypes.c_void_p(buf.data_ptr() + 4), ctypes.c_void_p(buf.data_ptr() + 8),
              _stream())
     return buf[1], buf[2]
+
+
+def grad_clip_coef(grads, max_norm):
+    """clip_grad_norm_ on the device: -> (total_norm, coef) f32 device scalars, coef = min(1, max_norm / (norm + 1e-6))."""
+    return clip_coef(grad_sqnorm(grads), max_norm)
+
+
+def reduce_shards(pieces, world, out=None, scale=None, out_dtype=None):
+    """out[i] = scale * sum_w pieces[w*n + i] (scale defaults to 1/world): the local sum of a one-hop reduce-scatter."""
+    if pieces.dtype not in (f32, bf16) or not pieces.is_contiguous() or not pieces.is_cuda:
+        raise RuntimeError("reduce_shards: pieces must be a contiguous f32 / bf16 GPU tensor")
+    n = pieces.numel() // world
+    if n * world != pieces.numel():
+        raise RuntimeError("reduce_shards: numel must be a multiple of world")
+    if out is None:
+        out = torch.empty(n, device=pieces.device, dtype=out_dtype or pieces.dtype)
+    lib.call("clipa_reduce_shards", _p(pieces), _p(out), n, int(world), int(pieces.dtype == f32), int(out.dtype == f32),
+             float(1.0 / world if scale is None else scale), _stream())
+    return out

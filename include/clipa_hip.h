@@ -104,11 +104,22 @@ int clipa_attention_bwd(const void* q, const void* k, const void* v, const void*
  * order, optional (x/255 - mean)/std (train.py:191-197 + conv1 im2col, transformer.py:371,491-493). */
 int clipa_patchify(const void* img, void* out, int64_t B, int64_t S, int64_t P, int64_t Kp, int in_dtype,
                    int nhwc, int normalize, const float* mean3, const float* std3, void* stream);
+/* Device-side train transform on uint8 NHWC batches (replaces the per-sample CPU work of
+ * open_clip/transform.py:152-168 after the H2D copy of training/train.py:187-189): out[b] = Grayscale?(resize(crop(src[b],
+ * box[b]), S x S, BICUBIC)) bit-exact with Pillow's ImagingResample / rgb2l (what torchvision's RandomResizedCrop and
+ * Grayscale(3) run on PIL images).  src [B,Hs,Ws,3], out [B,S,S,3]; boxes int32 [B][4] = (top, left, height, width), sampled
+ * by the caller; gray_flags uint8 [B] or NULL; err_count (device int32, may be NULL) counts rejected samples (box outside the
+ * image, or a down-scale above 11x) whose output is zeros. */
+int64_t clipa_resized_crop_workspace(int64_t B, int64_t Hs, int64_t S);
+int clipa_resized_crop_u8(const void* src, const int32_t* boxes, const uint8_t* gray_flags, void* out, int64_t B, int64_t Hs,
+                          int64_t Ws, int64_t S, void* workspace, int64_t workspace_bytes, int32_t* err_count, void* stream);
 /* cat(class_embedding) + positional_embedding (transformer.py:496-499) and its gradient. */
 int clipa_assemble_tokens(const void* patch, const float* cls, const float* pos, void* tokens, int64_t B,
                           int64_t L, int64_t D, void* stream);
+/* the batch sums (dcls, dpos) go through per-chunk partials in `workspace` and a fixed-order reduce: bit-reproducible */
+int64_t clipa_assemble_tokens_bwd_workspace(int64_t B, int64_t L, int64_t D);
 int clipa_assemble_tokens_bwd(const void* dtokens, void* dpatch, float* dcls, float* dpos, int64_t B,
-                              int64_t L, int64_t D, void* stream);
+                              int64_t L, int64_t D, void* workspace, int64_t workspace_bytes, void* stream);
 /* token_embedding(text) + positional_embedding (model.py:245-247) and gradients (dense f32 table grad). */
 int clipa_embed_tokens(const int64_t* ids, const void* table, int table_bf16, const float* pos, void* out,
                        int64_t B, int64_t T, int64_t D, int64_t vocab, int32_t* oob_count, void* stream);
@@ -116,7 +127,8 @@ int clipa_embed_tokens(const int64_t* ids, const void* table, int table_bf16, co
  * those; the forward substitutes row 0, the backward skips the row, the caller turns a non-zero count into an error
  * (clipa_amd.ops checks it asynchronously). */
 int clipa_embed_tokens_bwd(const int64_t* ids, const void* dx, float* dtable, float* dpos, int64_t B,
-                           int64_t T, int64_t D, int64_t vocab, int32_t* oob_count, void* stream);
+                           int64_t T, int64_t D, int64_t vocab, int32_t* oob_count, void* workspace,
+                           int64_t workspace_bytes, void* stream);   /* workspace: clipa_assemble_tokens_bwd_workspace(B, T, D) when dpos */
 /* text.argmax(dim=-1) (model.py:254) */
 int clipa_argmax_tokens(const int64_t* ids, int32_t* out, int64_t B, int64_t T, void* stream);
 /* pooling [B,L,D] bf16 -> [B,D] f32 and its gradient (writes all of dx) */
@@ -176,6 +188,11 @@ int clipa_adamw_multi(void* const* params, const void* const* grads, float* cons
 int clipa_grad_sqnorm_multi(const void* const* grads, const int64_t* numel, int count, int grad_f32, float* acc,
                             void* stream);
 int clipa_clip_coef(const float* acc, float max_norm, float* norm_out, float* coef_out, void* stream);
+/* Sharded gradient exchange (replaces the ring all-reduce of the DDP wrapper, training/main.py:292-299):
+ * out[i] = scale * sum over w < W of in[w*n + i] - the local sum of the W shard pieces a rank receives in the one-hop
+ * all-to-all form of a reduce-scatter (scale = 1/W: DDP's gradient average).  bf16 or f32 in / out, fp32 sums in rank
+ * order; n % 8 == 0. */
+int clipa_reduce_shards(const void* in, void* out, int64_t n, int W, int in_f32, int out_f32, float scale, void* stream);
 
 #ifdef __cplusplus
 }

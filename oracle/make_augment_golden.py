@@ -1,0 +1,39 @@
+"""Generate tests/golden/resized_crop_pil.npz from Pillow itself - the library torchvision's RandomResizedCrop / Grayscale
+call on the PIL images of the reference's train transform (clipa_torch/open_clip/transform.py:152-168).  Pillow is not
+vendored under /root/reference (third-party, unpinned there); the version that produced the fixture is stored in it.
+    python oracle/make_augment_golden.py
+Small on purpose (a few 96 x 128 images, crops resized to 32 / 56): the fixture pins oracle/resize_oracle.py and, through
+it, the HIP kernels; the tests additionally compare with the live Pillow whenever it is importable."""
+import os
+
+import numpy as np
+import PIL
+from PIL import Image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    rng = np.random.default_rng(20260926)
+    H, W, N = 96, 128, 6
+    imgs = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    imgs[0] = np.stack([yy * 255 // H, xx * 255 // W, (yy + xx) * 255 // (H + W)], -1).astype(np.uint8)   # smooth ramps
+    imgs[1] = ((yy // 4 + xx // 4) % 2 * 255)[..., None].repeat(3, -1).astype(np.uint8)                      # checkerboard
+    boxes = np.array([[0, 0, 96, 128], [10, 20, 40, 64], [30, 5, 66, 50], [0, 64, 96, 64], [7, 3, 32, 32], [50, 100, 20, 28]],
+                     np.int32)                                                                              # top, left, h, w
+    out = {}
+    for S in (32, 56):
+        res = np.zeros((N, S, S, 3), np.uint8)
+        for i in range(N):
+            t, l, h, w = (int(v) for v in boxes[i])
+            res[i] = np.asarray(Image.fromarray(imgs[i]).crop((l, t, l + w, t + h)).resize((S, S), Image.BICUBIC))
+        out[f"resized_{S}"] = res
+    gray = np.stack([np.asarray(Image.fromarray(im).convert("L").convert("RGB")) for im in imgs])
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "resized_crop_pil.npz"), images=imgs, boxes=boxes, gray=gray,
+                        pillow_version=np.array(PIL.__version__), **out)
+    print("wrote resized_crop_pil.npz with Pillow", PIL.__version__)
+
+
+if __name__ == "__main__":
+    main()

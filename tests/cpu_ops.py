@@ -239,6 +239,27 @@ def adamw_multi_(params, grads, exp_avgs, exp_avg_sqs, grad_scale_dev=None, clam
             p.clamp_(clamp[0], clamp[1])
 
 
+def grad_sqnorm(grads, buf=None):
+    if buf is None:
+        buf = torch.zeros(3)
+    buf[0] += sum((g.float() ** 2).sum() for g in grads)
+    return buf
+
+
+def clip_coef(buf, max_norm):
+    buf[1] = torch.sqrt(buf[0])
+    buf[2] = torch.clamp(max_norm / (buf[1] + 1e-6), max=1.0)
+    return buf[1], buf[2]
+
+
 def grad_clip_coef(grads, max_norm):
-    norm = torch.sqrt(sum((g.float() ** 2).sum() for g in grads))
-    return norm, torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+    return clip_coef(grad_sqnorm(grads), max_norm)
+
+
+def reduce_shards(pieces, world, out=None, scale=None, out_dtype=None):
+    n = pieces.numel() // world
+    r = pieces.float().view(world, n).sum(0) * (1.0 / world if scale is None else scale)
+    if out is None:
+        return r.to(out_dtype or pieces.dtype)
+    out.copy_(r)
+    return out

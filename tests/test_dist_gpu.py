@@ -188,6 +188,133 @@ def test_rccl_backend_single_rank_collectives_and_ddp():
     assert p.exitcode == 0
 
 
+def _sharded_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, ROOT)
+    import clipa_amd
+    from clipa_amd.zero import ShardedAdamW
+    model = _build(dev)
+    opt = ShardedAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3, betas=(0.9, 0.95), eps=1e-6, weight_decay=0.1,
+                       grad_clip_norm=1.0, bucket_bytes=8 << 20)
+    loss_fn = clipa_amd.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True, rank=rank, world_size=world)
+    img, txt = _batch(world)
+    img = img[rank * B_LOC:(rank + 1) * B_LOC].to(dev)
+    txt = txt[rank * B_LOC:(rank + 1) * B_LOC].to(dev)
+    losses = []
+    for _ in range(2):
+        opt.zero_grad()
+        out = model(img, txt)                 # no DDP wrapper: the optimizer's gradient hooks run the exchange
+        loss = loss_fn(**out, output_dict=True)["contrastive_loss"]
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    torch.cuda.synchronize()
+    q.put((rank, losses, {n: p.detach().float().cpu().numpy() for n, p in model.named_parameters()}, float(opt.last_grad_norm)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_optimizer_equals_global_batch_adamw():
+    """clipa_amd.zero.ShardedAdamW (gradient reduce-scatter + sharded AdamW state + parameter all-gather in
+    place of DDP + a full optimizer per rank) on the HIP kernels: two ranks end with identical weights that follow the
+    single-process global-batch AdamW run."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, 29781, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, losses, params, norm = _get(q, procs)
+        got[rank] = (losses, params, norm)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    import clipa_amd
+    from clipa_amd.optim import AdamW
+    dev = torch.device("cuda", 0)
+    model = _build(dev)
+    opt = AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3, betas=(0.9, 0.95), eps=1e-6, weight_decay=0.1,
+                grad_clip_norm=1.0)
+    img, txt = _batch(world)
+    ref_losses = []
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        out = model(img.to(dev), txt.to(dev))
+        loss = clipa_amd.ClipLoss()(**out, output_dict=True)["contrastive_loss"]
+        loss.backward()
+        opt.step()
+        ref_losses.append(float(loss.detach()))
+    for n, p in model.named_parameters():
+        a, b = got[0][1][n], got[1][1][n]
+        assert (a == b).all(), f"ranks disagree on {n} after the parameter all-gather"
+        # AdamW's normalised update moves a weight by at most ~lr per step whatever the gradient's size
+        assert abs(torch.from_numpy(a) - p.detach().float().cpu()).max() <= 2.5e-3, n
+    for k in range(2):
+        mean_local = 0.5 * (got[0][0][k] + got[1][0][k])
+        assert abs(mean_local - ref_losses[k]) <= 5e-3 * abs(ref_losses[k]), (k, mean_local, ref_losses[k])
+    assert abs(got[0][2] - got[1][2]) < 1e-5 and abs(got[0][2] - float(opt.last_grad_norm)) < 0.03 * float(opt.last_grad_norm)
+
+
+def _rccl_sharded_worker(port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    import sys
+    sys.path.insert(0, ROOT)
+    import clipa_amd
+    from clipa_amd.optim import AdamW
+    from clipa_amd.zero import ShardedAdamW
+    img, txt = _batch(1)
+    img, txt = img.to(dev), txt.to(dev)
+    res = {}
+    # without clipping the update is elementwise: bit-equal to the plain optimizer; with clipping the norm is summed in a
+    # different order (shards vs tensors), so the coefficient may differ in its last bit: one bf16 ulp of slack there
+    for clip in (None, 1.0):
+        for mode in ("plain", "reduce_scatter", "all_to_all"):
+            model = _build(dev, precision="bf16")            # pure-bf16 parameters and gradients, as bench.py trains
+            params = [p for p in model.parameters() if p.requires_grad]
+            kw = dict(lr=1e-3, betas=(0.9, 0.95), eps=1e-6, weight_decay=0.1, grad_clip_norm=clip)
+            opt = AdamW(params, **kw) if mode == "plain" else ShardedAdamW(params, bucket_bytes=8 << 20, exchange=mode,
+                                                                           force_collectives=True, **kw)
+            for _ in range(2):
+                opt.zero_grad()
+                out = model(img, txt)
+                loss = clipa_amd.ClipLoss(local_loss=True, gather_with_grad=True, rank=0, world_size=1)(**out, output_dict=True)["contrastive_loss"]
+                loss.backward()
+                opt.step()
+            torch.cuda.synchronize()
+            res[(clip, mode)] = {n: p.detach().float().cpu() for n, p in model.named_parameters()}
+    ok = True
+    for m in ("reduce_scatter", "all_to_all"):
+        for n, ref in res[(None, "plain")].items():
+            ok = ok and bool(torch.equal(ref, res[(None, m)][n]))
+        for n, ref in res[(1.0, "plain")].items():
+            ok = ok and bool(((ref - res[(1.0, m)][n]).abs() <= ref.abs() * 2.0 ** -7 + 1e-6).all())
+    q.put(bool(ok))
+    dist.destroy_process_group()
+
+
+def test_rccl_single_rank_sharded_optimizer_collectives():
+    """The RCCL call sequence of ShardedAdamW - reduce_scatter_tensor(AVG) on bf16 buckets, all_to_all_single + the
+    clipa_reduce_shards kernel, the scalar all-reduce of the clip norm, the in-place all_gather_into_tensor - on a 1-rank
+    group, where every collective is a copy: the result must equal the plain fused AdamW bit for bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_sharded_worker, args=(29783, q))
+    p.start()
+    assert _get(q, [p]) is True
+    p.join(timeout=120)
+    assert p.exitcode == 0
+
+
 def _variant_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -38,7 +38,24 @@ for s in $STAGES; do
         [ -n "$db" ] && python tools/rocpd_stats.py "$db" >> gpurun_out/pmc2_durations.txt 2>&1
       done ;;
     bench)
-      timeout 900 python bench.py > gpurun_out/bench.log 2>&1; echo "rc=$?" >> gpurun_out/bench.log ;;
+      timeout 900 python bench.py --shapes > gpurun_out/bench.log 2>&1; echo "rc=$?" >> gpurun_out/bench.log ;;
+    sharded)
+      # pre-flight of the sharded optimizer's RCCL call sequence inside the real step (1-rank group, forced collectives)
+      CLIPA_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 \
+        --master-port 29611 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --h2d-steps 0 --optimizer sharded \
+        > gpurun_out/bench_sharded.log 2>&1
+      echo "rc=$?" >> gpurun_out/bench_sharded.log ;;
+    alltests)
+      timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+      echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log ;;
+    profh14)
+      mkdir -p gpurun_out/prof_h14
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_h14" -o r02h14 -- \
+         python "$R/bench.py" --model ViT-H-14 --batch 2048 --precision fp8 --steps 2 --warmup 1 --no-cpu-baseline --h2d-steps 0 \
+         > "$R/gpurun_out/prof_h14_bench.log" 2>&1)
+      echo "rc=$?" >> gpurun_out/prof_h14_bench.log
+      db=$(find gpurun_out/prof_h14 -name '*.db' | head -1)
+      [ -n "$db" ] && python tools/rocpd_stats.py "$db" gpurun_out/prof_h14_kernel_stats.csv > gpurun_out/prof_h14_kernel_stats.txt 2>&1 ;;
     prof)
       mkdir -p gpurun_out/prof
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof" -o r02 -- \
@@ -52,4 +69,7 @@ echo "=== fp8 tests"; tail -n 30 gpurun_out/pytest_fp8.log 2>/dev/null
 echo "=== all gpu tests"; tail -n 8 gpurun_out/pytest_gpu.log 2>/dev/null
 echo "=== f8 bench"; cat gpurun_out/f8_bench.jsonl 2>/dev/null; tail -n 3 gpurun_out/f8_bench.err 2>/dev/null
 echo "=== h14"; tail -n 2 gpurun_out/bench_h14_fp8.log 2>/dev/null | cut -c1-1500; tail -n 2 gpurun_out/bench_h14_bf16.log 2>/dev/null | cut -c1-1500
-echo "=== pmc"; cat gpurun_out/pmc2_summary.txt 2>/dev/null | head -40
+echo "=== bench"; tail -n 3 gpurun_out/bench.log 2>/dev/null | cut -c1-3000
+echo "=== l16 fp8"; tail -n 2 gpurun_out/bench_l16_fp8.log 2>/dev/null | cut -c1-1500
+echo "=== sharded"; tail -n 3 gpurun_out/bench_sharded.log 2>/dev/null | cut -c1-1500
+echo "=== prof h14"; head -n 14 gpurun_out/prof_h14_kernel_stats.txt 2>/dev/null
