@@ -12,6 +12,8 @@ Activation policy: a block keeps only its bf16 input and recomputes the rest in 
 reference does with --grad-checkpointing, transformer.py:320-325), so ViT-L/16 at local batch 4096
 (806 912 tokens) fits in HBM with whole-batch GEMMs (M = 806 912) instead of micro-batches.
 """
+import weakref
+
 import torch
 
 from . import ops
@@ -22,7 +24,9 @@ bf16, f32 = torch.bfloat16, torch.float32
 class WeightCache:
     """bf16 operand copies of the parameters ([N,K] forward form and [K,N] transposed form for the
     input-gradient GEMMs), refreshed when the parameter's version counter changes (i.e. once per
-    optimizer step)."""
+    optimizer step).  An entry is valid for (this parameter object, its version counter, its storage address): writes
+    that go through `p.data` (EMA, manual weight surgery) bump no counter - call `clear()` (CLIP.invalidate_weight_cache)
+    after such writes; `load_state_dict` does it by itself."""
 
     def __init__(self):
         self._c = {}
@@ -31,9 +35,9 @@ class WeightCache:
         key = (id(p), kind)
         ver = p._version
         ent = self._c.get(key)
-        if ent is None or ent[0] != ver or ent[1] != p.data_ptr():
+        if ent is None or ent[0] != ver or ent[1] != p.data_ptr() or ent[3]() is not p:   # id() may be recycled: weakref check
             with torch.no_grad():
-                ent = (ver, p.data_ptr(), make(p.detach()))
+                ent = (ver, p.data_ptr(), make(p.detach()), weakref.ref(p))
             self._c[key] = ent
         return ent[2]
 

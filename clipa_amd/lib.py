@@ -37,6 +37,7 @@ SIGNATURES = {
     "clipa_assemble_tokens_bwd_workspace": (_I64, [_I64, _I64, _I64]),
     "clipa_assemble_tokens_bwd": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _I64, _P]),
     "clipa_embed_tokens": (_I32, [_P, _P, _I32, _P, _P, _I64, _I64, _I64, _I64, _P, _P]),
+    "clipa_embed_tokens_bwd_workspace": (_I64, [_I64, _I64, _I64, _I64, _I32, _I32]),
     "clipa_embed_tokens_bwd": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P]),
     "clipa_argmax_tokens": (_I32, [_P, _P, _I64, _I64, _P]),
     "clipa_pool_fwd": (_I32, [_P, _P, _P, _I64, _I64, _I64, _I32, _P]),

@@ -310,6 +310,12 @@ class CLIP(nn.Module):
             self.attn_mask = None
         self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
         self._init_text_parameters()
+        # operand copies (bf16 / transposed / fp8) are cached per parameter version: drop them whenever weights are loaded
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module._cache.clear())
+
+    def invalidate_weight_cache(self):
+        """Call after writing weights through `p.data` (EMA, weight surgery): such writes bump no version counter."""
+        self._cache.clear()
 
     def _init_text_parameters(self):
         """TextTransformer.init_parameters (transformer.py:596-612)."""

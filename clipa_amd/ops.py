@@ -399,8 +399,8 @@ def embed_tokens_bwd(ids, dx, vocab, need_table=True, need_pos=True):
     dtable = torch.empty((vocab, D), device=dx.device, dtype=f32) if need_table else None
     dpos = torch.empty((T, D), device=dx.device, dtype=f32) if need_pos else None
     oob = _oob_counter(ids.device)
-    wsb = lib.query("clipa_assemble_tokens_bwd_workspace", B, T, D) if need_pos else 0
-    ws = torch.empty(max(wsb, 4) // 4, device=dx.device, dtype=f32)
+    wsb = lib.query("clipa_embed_tokens_bwd_workspace", B, T, D, vocab, int(need_table), int(need_pos))
+    ws = torch.empty(max(wsb, 8) // 8, device=dx.device, dtype=torch.int64)
     lib.call("clipa_embed_tokens_bwd", _p(ids), _p(dx), _p(dtable), _p(dpos), B, T, D, vocab, _p(oob), _p(ws), wsb, _stream())
     _oob_submit(oob, "embed_tokens_bwd")
     return dtable, dpos

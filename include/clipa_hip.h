@@ -126,9 +126,12 @@ int clipa_embed_tokens(const int64_t* ids, const void* table, int table_bf16, co
 /* oob_count (device int32, may be NULL): incremented once per token id outside [0, vocab) - nn.Embedding raises on
  * those; the forward substitutes row 0, the backward skips the row, the caller turns a non-zero count into an error
  * (clipa_amd.ops checks it asynchronously). */
+/* The table gradient is a scatter-add on 64-bit fixed-point accumulators in `workspace` (integer atomics commute: the
+ * result is bit-reproducible), converted to f32 at the end; dpos goes through clipa_assemble_tokens_bwd's ordered sums. */
+int64_t clipa_embed_tokens_bwd_workspace(int64_t B, int64_t T, int64_t D, int64_t vocab, int need_table, int need_pos);
 int clipa_embed_tokens_bwd(const int64_t* ids, const void* dx, float* dtable, float* dpos, int64_t B,
                            int64_t T, int64_t D, int64_t vocab, int32_t* oob_count, void* workspace,
-                           int64_t workspace_bytes, void* stream);   /* workspace: clipa_assemble_tokens_bwd_workspace(B, T, D) when dpos */
+                           int64_t workspace_bytes, void* stream);
 /* text.argmax(dim=-1) (model.py:254) */
 int clipa_argmax_tokens(const int64_t* ids, int32_t* out, int64_t B, int64_t T, void* stream);
 /* pooling [B,L,D] bf16 -> [B,D] f32 and its gradient (writes all of dx) */

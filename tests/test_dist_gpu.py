@@ -292,13 +292,16 @@ def _rccl_sharded_worker(port, q):
                 opt.step()
             torch.cuda.synchronize()
             res[(clip, mode)] = {n: p.detach().float().cpu() for n, p in model.named_parameters()}
-    ok = True
+    bad = []
     for m in ("reduce_scatter", "all_to_all"):
         for n, ref in res[(None, "plain")].items():
-            ok = ok and bool(torch.equal(ref, res[(None, m)][n]))
+            if not torch.equal(ref, res[(None, m)][n]):
+                bad.append((m, "no clip", n, float((ref - res[(None, m)][n]).abs().max())))
         for n, ref in res[(1.0, "plain")].items():
-            ok = ok and bool(((ref - res[(1.0, m)][n]).abs() <= ref.abs() * 2.0 ** -7 + 1e-6).all())
-    q.put(bool(ok))
+            d = (ref - res[(1.0, m)][n]).abs()
+            if not bool((d <= ref.abs() * 2.0 ** -7 + 1e-6).all()):
+                bad.append((m, "clip", n, float(d.max())))
+    q.put(bad[:8] if bad else True)
     dist.destroy_process_group()
 
 
@@ -310,7 +313,8 @@ def test_rccl_single_rank_sharded_optimizer_collectives():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_sharded_worker, args=(29783, q))
     p.start()
-    assert _get(q, [p]) is True
+    got = _get(q, [p])
+    assert got is True, got
     p.join(timeout=120)
     assert p.exitcode == 0
 

@@ -128,12 +128,6 @@ def test_recompute_equals_stored_activations(golden):
         ga[rc] = (float(loss), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
     assert ga[True][0] == ga[False][0] == ga["mixed"][0]
     for k in ga[True][1]:
-        if k == "token_embedding.weight":
-            # the one gradient that is a scatter-add of float atomics (embed_tokens_bwd): summation order, hence the last
-            # bits, may differ from run to run - independent of the keep policy under test
-            assert torch.allclose(ga[True][1][k], ga[False][1][k], rtol=1e-5, atol=1e-7), k
-            assert torch.allclose(ga[True][1][k], ga["mixed"][1][k], rtol=1e-5, atol=1e-7), k
-            continue
         assert torch.equal(ga[True][1][k], ga[False][1][k]), k
         assert torch.equal(ga[True][1][k], ga["mixed"][1][k]), k
 

@@ -48,6 +48,8 @@ for s in $STAGES; do
     alltests)
       timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
       echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log ;;
+    attnab)
+      timeout 300 python tools/attn_ab.py > gpurun_out/attn_ab.jsonl 2> gpurun_out/attn_ab.err ;;
     profh14)
       mkdir -p gpurun_out/prof_h14
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_h14" -o r02h14 -- \
@@ -72,4 +74,5 @@ echo "=== h14"; tail -n 2 gpurun_out/bench_h14_fp8.log 2>/dev/null | cut -c1-150
 echo "=== bench"; tail -n 3 gpurun_out/bench.log 2>/dev/null | cut -c1-3000
 echo "=== l16 fp8"; tail -n 2 gpurun_out/bench_l16_fp8.log 2>/dev/null | cut -c1-1500
 echo "=== sharded"; tail -n 3 gpurun_out/bench_sharded.log 2>/dev/null | cut -c1-1500
+echo "=== attn ab"; cat gpurun_out/attn_ab.jsonl 2>/dev/null; tail -n 3 gpurun_out/attn_ab.err 2>/dev/null
 echo "=== prof h14"; head -n 14 gpurun_out/prof_h14_kernel_stats.txt 2>/dev/null
