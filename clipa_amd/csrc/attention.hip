@@ -17,11 +17,8 @@
 // ds_read_b64_tr_b16.  The backward pass is two sweeps (query-major for dQ, key-major for dK/dV)
 // that recompute the probabilities from per-row (max, 1/sum) statistics kept in LDS.
 #include "common.h"
-#include <atomic>
 #include <mutex>
 #include "clipa_hip.h"
-
-namespace clipa_gemm { extern std::atomic<int> g_abl; }   // experiment flags of clipa_debug_set (gemm_nt.hip)
 
 namespace {
 
@@ -255,11 +252,10 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_fwd_kernel(AttnArgs p) 
 //   phase 1: K, V images; query-major sweep -> dQ   (q / dO / O rows of the wave's tile come from global)
 //   phase 2: Q, dO images; key-major sweep   -> dK, dV (k / v rows of the wave's tile come from global)
 // Probabilities are recomputed from the forward's (c*rowmax, 1/rowsum) statistics; D_q = <dO_q, O_q>.
-// PIPE: both sweeps are software-pipelined inside the wave - the score / dP MFMAs of tile pair i+1 are issued BEFORE the
-// softmax-gradient arithmetic of pair i, so the matrix pipe works under the VALU block instead of idling behind it (a wave
-// issues in order; with two waves per SIMD the other wave alone covered only part of it: the kernel sat at ~25 % MFMA
-// busy).  Same operations in the same accumulation order: results are bit-identical to the plain schedule.
-template <int NKT, int DH, bool CAUSAL, bool PIPE>
+// (A software-pipelined variant - next pair's score MFMAs / previous pair's dK,dV MFMAs issued ahead of the softmax-gradient
+// arithmetic, bit-identical results - measured 2-14 % SLOWER on every production shape and was dropped:
+// profiles/r02_attention_bwd_pipelining_ab.jsonl.  The kernel moves ~13 GB per launch; it is not issue-bound.)
+template <int NKT, int DH, bool CAUSAL>
 __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) {
   constexpr int LP = NKT * 32, RB = HD<DH>::RB, KS = HD<DH>::KS, DT = HD<DH>::DT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -323,46 +319,6 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
-    if constexpr (PIPE) {
-      const int kt_last = CAUSAL ? qt : NKT - 1;
-      auto scores = [&](int kt, f32x16& s_, f32x16& dp_) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s_[r] = 0.f; dp_[r] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          s_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct<DH>(img0, 32 * kt, l31, hi, ks), fq[ks], s_, 0, 0, 0);
-          dp_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct<DH>(img1, 32 * kt, l31, hi, ks), fdo[ks], dp_, 0, 0, 0);
-        }
-      };
-      auto pair = [&](int kt, const f32x16& s_, const f32x16& dp_, f32x16& sn, f32x16& dpn) {
-        if (kt < kt_last) scores(kt + 1, sn, dpn);
-        __builtin_amdgcn_sched_barrier(0);
-        const bool full = CAUSAL ? ((32 * kt + 32 <= p.L) && kt < qt) : (kt < NKT - 1);
-        float ds[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float pe = __builtin_amdgcn_exp2f(fmaf(s_[r], c, -st.x)) * st.y;
-          if (!full) pe = (32 * kt + 8 * (r >> 2) + (r & 3) < lim2) ? pe : 0.f;
-          ds[r] = pe * (dp_[r] - Dq) * p.scale;
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const bf16x8 dsf = pack_frag(ds + 8 * s2);
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt)
-            dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans<DH>(img0, 32 * kt + 16 * s2, 32 * dt, hi, q16, i16), dsf, dq[dt], 0, 0, 0);
-        }
-      };
-      f32x16 sA, dpA, sB, dpB;
-      scores(0, sA, dpA);
-#pragma nounroll
-      for (int kt = 0;;) {
-        pair(kt, sA, dpA, sB, dpB);
-        if (++kt > kt_last) break;
-        pair(kt, sB, dpB, sA, dpA);
-        if (++kt > kt_last) break;
-      }
-    } else
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       if (CAUSAL && kt > qt) continue;
@@ -418,59 +374,6 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
-    if constexpr (PIPE) {
-      // dK / dV MFMAs of query tile i-1 are issued right before the softmax-gradient arithmetic of tile i and execute
-      // under it (their operands, the packed P / dS fragments of tile i-1, cost 16 registers); accumulation order unchanged
-      bf16x8 pfp[2], dsfp[2];
-      auto dkdv = [&](int qt) {
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans<DH>(img1, 32 * qt + 16 * s2, 32 * dt, hi, q16, i16), pfp[s2], dv[dt], 0, 0, 0);
-            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans<DH>(img0, 32 * qt + 16 * s2, 32 * dt, hi, q16, i16), dsfp[s2], dk[dt], 0, 0, 0);
-          }
-      };
-      const int q_first = CAUSAL ? kt : 0;
-#pragma nounroll
-      for (int qt = q_first; qt < NKT; ++qt) {
-        f32x16 s, dp;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct<DH>(img0, 32 * qt, l31, hi, ks), fk[ks], s, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct<DH>(img1, 32 * qt, l31, hi, ks), fv[ks], dp, 0, 0, 0);
-        }
-        if (qt > q_first) dkdv(qt - 1);
-        __builtin_amdgcn_sched_barrier(0);
-        float pr[16], ds[16];
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          const int q0 = 32 * qt + 8 * rq + 4 * hi;
-          const float4 m4 = *(const float4*)(sM + q0);
-          const float4 l4 = *(const float4*)(sL + q0);
-          const float4 d4 = *(const float4*)(sD + q0);
-          const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
-          const float ll[4] = {l4.x, l4.y, l4.z, l4.w};
-          const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * rq + e;
-            float pe = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mm[e])) * ll[e];
-            if (CAUSAL && qt == kt) pe = (kgc <= 8 * rq + e) ? pe : 0.f;
-            pr[r] = pe;
-            ds[r] = pe * (dp[r] - dd[e]) * p.scale;
-          }
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          pfp[s2] = pack_frag(pr + 8 * s2);
-          dsfp[s2] = pack_frag(ds + 8 * s2);
-        }
-      }
-      dkdv(NKT - 1);
-    } else
     for (int qt = (CAUSAL ? kt : 0); qt < NKT; ++qt) {
       f32x16 s, dp;
 #pragma unroll
@@ -836,8 +739,8 @@ template <int NKT, int DH>
 int launch_fwd(const AttnArgs& a, hipStream_t st) {
   return a.causal ? launch_fwd_c<NKT, DH, true>(a, st) : launch_fwd_c<NKT, DH, false>(a, st);
 }
-template <int NKT, int DH, bool CAUSAL, bool PIPE>
-int launch_bwd_cp(const AttnArgs& a, hipStream_t st) {
+template <int NKT, int DH, bool CAUSAL>
+int launch_bwd_c(const AttnArgs& a, hipStream_t st) {
   constexpr int HPW = WGHeads<NKT>::HPW;
   const int lds = HPW * (2 * NKT * 32 * HD<DH>::RB + 3 * NKT * 32 * 4);
   // the LDS opt-in is a per-device function attribute: once per (kernel instantiation, device), thread-safe (the
@@ -847,20 +750,13 @@ int launch_bwd_cp(const AttnArgs& a, hipStream_t st) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ATTN_MAX_DEVICES) { clipa_set_error("attn_bwd: bad device"); return CLIPA_ERR_LAUNCH; }
   std::call_once(once[dev], [&]() {
-    const hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NKT, DH, CAUSAL, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NKT, DH, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     rc_dev[dev] = 0;
     if (e != hipSuccess) { clipa_set_error("attn_bwd attr: %s", hipGetErrorString(e)); rc_dev[dev] = CLIPA_ERR_LAUNCH; }
   });
   if (rc_dev[dev]) return rc_dev[dev];
-  hipLaunchKernelGGL((attn_bwd_kernel<NKT, DH, CAUSAL, PIPE>), dim3((unsigned)(((long)a.B * a.H + HPW - 1) / HPW)), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((attn_bwd_kernel<NKT, DH, CAUSAL>), dim3((unsigned)(((long)a.B * a.H + HPW - 1) / HPW)), dim3(256), lds, st, a);
   return clipa_check_launch("attn_bwd");
-}
-// Experiment flag 16384 (clipa_debug_set) selects the plain (un-pipelined) schedule for in-process A/B runs and the
-// bit-equality test; production = pipelined for every shape with more than one tile pair per wave.
-template <int NKT, int DH, bool CAUSAL>
-int launch_bwd_c(const AttnArgs& a, hipStream_t st) {
-  if (NKT == 1 || (clipa_gemm::g_abl.load(std::memory_order_relaxed) & 16384)) return launch_bwd_cp<NKT, DH, CAUSAL, false>(a, st);
-  return launch_bwd_cp<NKT, DH, CAUSAL, true>(a, st);
 }
 template <int NKT, int DH>
 int launch_bwd(const AttnArgs& a, hipStream_t st) {

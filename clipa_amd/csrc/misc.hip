@@ -156,11 +156,14 @@ __global__ void embed_tokens_kernel(const long* __restrict__ ids, const void* __
 // causal mask - are skipped); dpos via assemble_tokens_bwd-style reduction is done by a second call.
 // The scatter-add runs on 64-bit FIXED-POINT integers (value * 2^44): integer atomics commute, so the table gradient is
 // bit-identical from run to run whatever order the rows arrive in (float atomics are not: the same step gave different
-// last bits on different runs).  bf16 inputs convert exactly (|v| < 2^19; anything below 2^-45 rounds to 0), the sum
-// is exact, and one rounding to f32 happens in the convert kernel.
+// last bits on different runs).  bf16 inputs convert exactly (anything below 2^-45 rounds to 0), the sum is exact, and
+// one rounding to f32 happens in the convert kernel.  Range: |element| <= 2^17, |sum| < 2^19 - far above any gradient
+// of a training run that has not diverged; rows that receive a non-finite element are flagged and come out as NaN (what
+// the float sum would give), an out-of-range element is treated the same way.
 constexpr double EMB_FIX = 17592186044416.0;         // 2^44
 __global__ void embed_tokens_bwd_kernel(const long* __restrict__ ids, const unsigned short* __restrict__ dx,
-                                        unsigned long long* __restrict__ acc, long B, int T, int D, int vocab, int* __restrict__ oob) {
+                                        unsigned long long* __restrict__ acc, unsigned char* __restrict__ bad_row, long B, int T,
+                                        int D, int vocab, int* __restrict__ oob) {
   const int dc = D / 8;
   const long total = B * T * dc;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -178,14 +181,15 @@ __global__ void embed_tokens_bwd_kernel(const long* __restrict__ ids, const unsi
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       if (v[i] == 0.f) continue;
-      const double q = fmin(fmax((double)v[i], -524287.0), 524287.0) * EMB_FIX;
-      atomicAdd(acc + (size_t)id * D + c * 8 + i, (unsigned long long)__double2ll_rn(q));
+      if (!(fabsf(v[i]) <= 131072.0f)) { bad_row[id] = 1; continue; }      // NaN / Inf / out of range: poison the row
+      atomicAdd(acc + (size_t)id * D + c * 8 + i, (unsigned long long)__double2ll_rn((double)v[i] * EMB_FIX));
     }
   }
 }
-__global__ void embed_fix_to_f32_kernel(const long long* __restrict__ acc, float* __restrict__ out, long n) {
+__global__ void embed_fix_to_f32_kernel(const long long* __restrict__ acc, const unsigned char* __restrict__ bad_row,
+                                        float* __restrict__ out, long n, int D) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    out[i] = (float)((double)acc[i] * (1.0 / EMB_FIX));
+    out[i] = bad_row[i / D] ? __int_as_float(0x7fc00000) : (float)((double)acc[i] * (1.0 / EMB_FIX));
 }
 
 // first-occurrence argmax over token ids (text.argmax(dim=-1), model.py:254)
@@ -477,7 +481,7 @@ extern "C" int clipa_embed_tokens(const int64_t* ids, const void* table, int tab
 
 extern "C" int64_t clipa_embed_tokens_bwd_workspace(int64_t B, int64_t T, int64_t D, int64_t vocab, int need_table,
                                                    int need_pos) {
-  int64_t w = need_table ? vocab * D * (int64_t)sizeof(long long) : 0;      // fixed-point accumulators of the table gradient
+  int64_t w = need_table ? vocab * D * (int64_t)sizeof(long long) + (vocab + 7) / 8 * 8 : 0;   // fixed-point accumulators + row flags
   const int64_t pw = need_pos ? clipa_assemble_tokens_bwd_workspace(B, T, D) : 0;
   return w > pw ? w : pw;                                                   // the two phases run one after the other
 }
@@ -493,10 +497,11 @@ extern "C" int clipa_embed_tokens_bwd(const int64_t* ids, const void* dx, float*
   }
   hipStream_t st = (hipStream_t)stream;
   if (dtable) {
-    (void)hipMemsetAsync(workspace, 0, vocab * D * sizeof(long long), st);
-    hipLaunchKernelGGL(embed_tokens_bwd_kernel, dim3(grid_for(B * T * (D / 8))), dim3(256), 0, st, (const long*)ids, (const unsigned short*)dx, (unsigned long long*)workspace, (long)B, (int)T, (int)D, (int)vocab, oob_count);
+    unsigned char* bad_row = (unsigned char*)workspace + vocab * D * sizeof(long long);
+    (void)hipMemsetAsync(workspace, 0, vocab * D * sizeof(long long) + (vocab + 7) / 8 * 8, st);
+    hipLaunchKernelGGL(embed_tokens_bwd_kernel, dim3(grid_for(B * T * (D / 8))), dim3(256), 0, st, (const long*)ids, (const unsigned short*)dx, (unsigned long long*)workspace, bad_row, (long)B, (int)T, (int)D, (int)vocab, oob_count);
     if (int rc = clipa_check_launch("embed_tokens_bwd")) return rc;
-    hipLaunchKernelGGL(embed_fix_to_f32_kernel, dim3(grid_for(vocab * D)), dim3(256), 0, st, (const long long*)workspace, dtable, (long)(vocab * D));
+    hipLaunchKernelGGL(embed_fix_to_f32_kernel, dim3(grid_for(vocab * D)), dim3(256), 0, st, (const long long*)workspace, bad_row, dtable, (long)(vocab * D), (int)D);
     if (int rc = clipa_check_launch("embed_tokens_bwd_convert")) return rc;
   }
   if (dpos) return clipa_assemble_tokens_bwd(dx, nullptr, nullptr, dpos, B, T, D, workspace, workspace_bytes, stream);

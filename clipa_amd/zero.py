@@ -6,8 +6,8 @@ every GPU, the same update computed W times).  `ShardedAdamW` replaces the pair 
 arithmetic:
 
   backward   gradients accumulate straight into flat per-bucket buffers; when a bucket is complete (autograd hooks, so the
-             exchange overlaps the rest of the backward pass) it is REDUCE-SCATTERED (AVG): rank r receives only the r-th
-             1/W of the averaged bucket.  `exchange="all_to_all"` does the same exchange as W-1 simultaneous one-hop peer
+             exchange overlaps the rest of the backward pass) it is REDUCE-SCATTERED (SUM; the 1/W of DDP's average is
+             applied inside the update kernel): rank r receives only the r-th 1/W of the bucket.  `exchange="all_to_all"` does the same exchange as W-1 simultaneous one-hop peer
              sends over the xGMI mesh (all_to_all_single) + a local fp32 sum (clipa_reduce_shards) instead of RCCL's
              reduce-scatter schedule - on MI355X every pair of GPUs has its own link, a ring uses one of seven;
   step       each rank updates ONLY its shard with the fused multi-tensor AdamW kernel (moments exist only for the shard:
@@ -131,7 +131,9 @@ class ShardedAdamW(torch.optim.Optimizer):
                 b.recv = torch.empty_like(b.grad)
             b.handle = dist.all_to_all_single(b.recv, b.grad, group=self.group, async_op=True)
         else:
-            b.handle = dist.reduce_scatter_tensor(b.gshard, b.grad, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            # SUM on the wire, the 1/W of DDP's average rides in the update kernel's grad_scale (as DDP pre-divides): RCCL's AVG
+            # path dropped the tail of an fp32 bucket on a 1-rank group (tools/zero_diag.py, profiles/r02_zero_diag.txt)
+            b.handle = dist.reduce_scatter_tensor(b.gshard, b.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _finish(self, b):
         if not b.launched:                                        # parameters that received no gradient this step, or no_sync
@@ -142,9 +144,8 @@ class ShardedAdamW(torch.optim.Optimizer):
             n = b.numel // self.world
             if not self._tensor_collectives:
                 b.gshard.copy_(b.grad[self.rank * n:(self.rank + 1) * n])
-                b.gshard.mul_(1.0 / self.world)
             elif self.exchange == "all_to_all":
-                ops.reduce_shards(b.recv, self.world, out=b.gshard)
+                ops.reduce_shards(b.recv, self.world, out=b.gshard, scale=1.0)
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -178,11 +179,15 @@ class ShardedAdamW(torch.optim.Optimizer):
                 loss = closure()
         for b in self.buckets:
             self._finish(b)
+        # the shards hold the SUM over ranks; DDP's average = sum / W is applied as grad_scale inside the update kernel
+        avg = 1.0 / self.world if self._collect else 1.0
         coef = None
         if self.grad_clip_norm is not None and self.buckets:
             buf = ops.grad_sqnorm([b.gshard for b in self.buckets])   # padding is zero: shards partition the gradient
             if self._collect:
                 dist.all_reduce(buf[0:1], op=dist.ReduceOp.SUM, group=self.group)
+            if avg != 1.0:
+                buf[0:1].mul_(avg * avg)                              # |g / W|^2
             self.last_grad_norm, coef = ops.clip_coef(buf, self.grad_clip_norm)
         self._steps += 1
         calls = {}
@@ -192,7 +197,7 @@ class ShardedAdamW(torch.optim.Optimizer):
             g = self.param_groups[gi]
             ops.adamw_multi_([b.shard for b in bs], [b.gshard for b in bs], [b.m for b in bs], [b.v for b in bs],
                              lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"],
-                             weight_decay=g["weight_decay"], step=self._steps, grad_scale_dev=coef)
+                             weight_decay=g["weight_decay"], step=self._steps, grad_scale=avg, grad_scale_dev=coef)
         if self._collect:
             handles = []
             for b in self.buckets:

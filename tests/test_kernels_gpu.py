@@ -242,25 +242,6 @@ def test_attention_long_sequences(B, H, L, causal, dh):
     check("dqkv", dq.reshape(B, L, 3 * D), x.grad, 2 ** -5, 2e-2)
 
 
-@pytest.mark.parametrize("B,H,L,causal,dh", [(3, 4, 197, False, 64), (5, 2, 77, True, 64), (2, 3, 257, False, 80), (4, 2, 50, True, 64),
-                                               (2, 2, 288, True, 64), (3, 2, 33, False, 80)])
-def test_attention_bwd_pipelined_schedule_is_bit_identical(B, H, L, causal, dh):
-    """The production backward issues the next tile pair's score MFMAs ahead of the current pair's softmax-gradient
-    arithmetic; operations and accumulation order are those of the plain schedule (experiment flag 16384)."""
-    o = ops()
-    D = H * dh
-    qkv = rnd(B * L, 3 * D, seed=L + dh).to(DEV)
-    out, st = o.attention_fwd(qkv, B, L, H, causal, want_stats=True)
-    dout = rnd(B * L, D, seed=7).to(DEV)
-    try:
-        _debug_set(0, 16384)
-        plain = o.attention_bwd(qkv, out, dout, st, B, L, H, causal)
-    finally:
-        _debug_set(0, 0)
-    piped = o.attention_bwd(qkv, out, dout, st, B, L, H, causal)
-    assert torch.equal(plain, piped)
-
-
 def test_embedding_gradient_is_bit_reproducible():
     """The token-embedding gradient is a scatter-add over ~B*ctx rows, most of them hitting a few ids (SOT / EOT): it runs on
     fixed-point integer atomics, so repeated launches agree bit for bit (float atomics do not)."""
@@ -269,13 +250,17 @@ def test_embedding_gradient_is_bit_reproducible():
     g = torch.Generator().manual_seed(0)
     ids = torch.randint(0, 8, (B, T), generator=g)                # heavy collisions
     ids[:, 0] = V - 2
-    dx = (torch.randn(B * T, D, generator=g) * torch.exp(torch.randn(B * T, 1, generator=g) * 4)).to(bf16)
+    dx = (torch.randn(B * T, D, generator=g) * torch.exp(torch.randn(B * T, 1, generator=g) * 4 - 8)).to(bf16)   # 1e-9 .. 30
     a, _ = o.embed_tokens_bwd(ids.to(DEV), dx.to(DEV), V)
     for _ in range(3):
         b, _ = o.embed_tokens_bwd(ids.to(DEV), dx.to(DEV), V)
         assert torch.equal(a, b)
     ref = torch.zeros(V, D, dtype=torch.float64).index_add_(0, ids.reshape(-1), dx.double())
-    check("dtable", a, ref, 1e-6, 1e-9)
+    check("dtable", a, ref, 1e-6, 1e-10)
+    dx[5, 3] = float("nan")                                           # a non-finite gradient poisons its table row, as a float sum would
+    c, _ = o.embed_tokens_bwd(ids.to(DEV), dx.to(DEV), V)
+    row = int(ids.reshape(-1)[5])
+    assert torch.isnan(c[row]).all() and torch.isfinite(c[[r for r in range(8) if r != row]]).all()
 
 
 @pytest.mark.parametrize("dh", [64, 80])
