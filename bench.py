@@ -279,7 +279,7 @@ def main():
 
     # PCIe-inclusive rate (the reference's batch_time includes the H2D copy, train.py:187-189): the same step
     # fed from pinned host memory with staged uint8 NHWC images through DevicePrefetcher (copy stream, double buffered) +
-    # the on-device RandomResizedCrop / Grayscale of the reference GPU recipe (scripts/exp/gpu/vit_l16/i37_t8_pretrain.sh:13).
+    # the on-device RandomResizedCrop / ColorJitter / Grayscale of the reference GPU recipe (scripts/exp/gpu/vit_l16/i37_t8_pretrain.sh:13).
     # Never part of `value`.
     h2d = None
     if args.h2d_steps > 0:
@@ -292,7 +292,8 @@ def main():
             texts_host = texts.cpu().pin_memory()
             n_h2d = args.h2d_steps
             loader = ((pool[i % 2], texts_host) for i in range(n_h2d + 1))
-            aug = DeviceAugment(args.image_size, scale=(0.4, 1.0), gray_scale_prob=0.2, seed=7 + rank)
+            aug = DeviceAugment(args.image_size, scale=(0.4, 1.0), color_jitter=(0.32, 0.32, 0.32, 0.08), color_jitter_prob=0.8,
+                                gray_scale_prob=0.2, seed=7 + rank)
             feed = iter(DevicePrefetcher(loader, dev, transform=aug, depth=2))
             step(*next(feed))                                                    # warm-up of the pipeline itself
             fence()
@@ -309,7 +310,7 @@ def main():
             h2d = {"value": round(B * world * n_h2d / eh, 2), "unit": "pairs/s", "ms_per_step": round(1e3 * eh / n_h2d, 2),
                    "steps": n_h2d, "loss": round(float(loss_h), 4),
                    "input": f"uint8 NHWC {stage}x{stage} staged images in pinned host memory -> DevicePrefetcher (depth 2, copy "
-                            f"stream) -> on-device RandomResizedCrop(scale 0.4-1, bicubic) + Grayscale(p=0.2) -> {args.image_size} px"}
+                            f"stream) -> on-device RandomResizedCrop(scale 0.4-1, bicubic) + ColorJitter(0.32, 0.32, 0.32, 0.08; p=0.8) + Grayscale(p=0.2) -> {args.image_size} px"}
             del pool, feed
         except (RuntimeError, torch.OutOfMemoryError) as e:                      # the headline line must survive
             h2d = {"value": None, "error": str(e)[:200]}

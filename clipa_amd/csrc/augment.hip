@@ -132,6 +132,111 @@ __global__ void rrc_vertical_kernel(const unsigned char* __restrict__ tmp, const
   o[0] = c0; o[1] = c1; o[2] = c2;
 }
 
+// ---- ColorJitter + Grayscale on the resized uint8 batch, in place ----------------------------------------------------------
+// torchvision ColorJitter on PIL images (open_clip/transform.py:61-72): brightness / contrast / saturation are Pillow's
+// Image.blend(degenerate, image, factor) - libImaging Blend.c: (UINT8)(in1 + alpha * (in2 - in1)) in C float, clipped when
+// alpha leaves [0, 1] - with degenerate = black / solid int(mean(L) + 0.5) / L; hue is convert('HSV'), h += uint8(f * 255),
+// convert('RGB') (Convert.c rgb2hsv_row / hsv2rgb: colorsys in mixed float / double).  The four run in a per-sample random
+// order, so the batch takes four passes: pass k applies every sample's k-th operation (preceded by the per-image sum of L
+// that a contrast step needs - integer atomics, exact).  Same float / double operations in the same order as the C code
+// (FMA contraction is off in this file): bit-exact against Pillow (oracle/color_oracle.py).
+__device__ __forceinline__ int rgb2l_i(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
+
+__device__ __forceinline__ unsigned char blend_u8(int d, int p, float a) {
+  const float t = (float)d + a * (float)(p - d);
+  if (a >= 0.f && a <= 1.f) return (unsigned char)(int)t;
+  return t <= 0.f ? (unsigned char)0 : (t >= 255.f ? (unsigned char)255 : (unsigned char)(int)t);
+}
+
+__device__ __forceinline__ int clip8i(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+__device__ void hue_u8(int& r, int& g, int& b, int shift) {
+  // rgb2hsv_row
+  const int maxc = max(r, max(g, b)), minc = min(r, min(g, b));
+  int uh = 0, us = 0;
+  const int uv = maxc;
+  if (minc != maxc) {
+    const float cr = (float)(maxc - minc);
+    const float sf = cr / (float)maxc;
+    const float rc = ((float)(maxc - r)) / cr, gc = ((float)(maxc - g)) / cr, bc = ((float)(maxc - b)) / cr;
+    float h;
+    if (r == maxc) h = bc - gc;
+    else if (g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
+    else h = (float)(4.0 + (double)gc - (double)rc);
+    h = (float)fmod((double)h / 6.0 + 1.0, 1.0);
+    uh = clip8i((int)((double)h * 255.0));
+    us = clip8i((int)((double)sf * 255.0));
+  }
+  uh = (uh + shift) & 0xff;
+  // hsv2rgb
+  if (us == 0) { r = g = b = uv; return; }
+  const double hf = (double)(float)uh * 6.0 / 255.0;
+  const int i = (int)floor(hf);
+  const float f = (float)(hf - (double)(float)i);
+  const float fs = (float)((double)(float)us / 255.0);
+  const double vf = (double)(float)uv;
+  const int p = clip8i((int)round(vf * (1.0 - (double)fs)));
+  const int q = clip8i((int)round(vf * (1.0 - (double)fs * (double)f)));
+  const int t = clip8i((int)round(vf * (1.0 - (double)fs * (1.0 - (double)f))));
+  switch (i % 6) {
+    case 0: r = uv; g = t; b = p; break;
+    case 1: r = q; g = uv; b = p; break;
+    case 2: r = p; g = uv; b = t; break;
+    case 3: r = p; g = q; b = uv; break;
+    case 4: r = t; g = p; b = uv; break;
+    default: r = uv; g = p; b = q; break;
+  }
+}
+
+// lsum[b] += sum over the image of L (only where sample b's operation of this pass is a contrast step)
+__global__ void jitter_lsum_kernel(const unsigned char* __restrict__ img, const unsigned char* __restrict__ apply,
+                                   const int* __restrict__ order, unsigned long long* __restrict__ lsum, int B, int S, int step) {
+  const int b = blockIdx.y;
+  if ((apply && !apply[b]) || order[b * 4 + step] != 1) return;
+  const long n = (long)S * S;
+  const unsigned char* im = img + (long)b * n * 3;
+  unsigned long long acc = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    acc += (unsigned long long)rgb2l_i(im[3 * i], im[3 * i + 1], im[3 * i + 2]);
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(lsum + b, acc);
+}
+
+__global__ void jitter_step_kernel(unsigned char* __restrict__ img, const unsigned char* __restrict__ apply,
+                                   const int* __restrict__ order, const float* __restrict__ factors,
+                                   const unsigned long long* __restrict__ lsum, int B, int S, int step) {
+  const long n = (long)S * S;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)B * n) return;
+  const int b = (int)(t / n);
+  if (apply && !apply[b]) return;
+  const int op = order[b * 4 + step];
+  const float f = factors[b * 4 + op];
+  unsigned char* px = img + t * 3;
+  int r = px[0], g = px[1], bl = px[2];
+  if (op == 0) {                 // brightness: blend with black
+    r = blend_u8(0, r, f); g = blend_u8(0, g, f); bl = blend_u8(0, bl, f);
+  } else if (op == 1) {          // contrast: blend with the solid mean-of-L image
+    const int mean = (int)((double)lsum[b] / (double)n + 0.5);
+    r = blend_u8(mean, r, f); g = blend_u8(mean, g, f); bl = blend_u8(mean, bl, f);
+  } else if (op == 2) {          // saturation: blend with L
+    const int l = rgb2l_i(r, g, bl);
+    r = blend_u8(l, r, f); g = blend_u8(l, g, f); bl = blend_u8(l, bl, f);
+  } else {                       // hue
+    hue_u8(r, g, bl, (int)((double)f * 255.0) & 0xff);      // torchvision: np.uint8(hue_factor * 255), a double product
+  }
+  px[0] = (unsigned char)r; px[1] = (unsigned char)g; px[2] = (unsigned char)bl;
+}
+
+__global__ void grayscale_kernel(unsigned char* __restrict__ img, const unsigned char* __restrict__ gray, int B, int S) {
+  const long n = (long)S * S;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)B * n || !gray[t / n]) return;
+  unsigned char* px = img + t * 3;
+  const unsigned char l = (unsigned char)rgb2l_i(px[0], px[1], px[2]);
+  px[0] = px[1] = px[2] = l;
+}
+
 }  // namespace
 
 extern "C" int64_t clipa_resized_crop_workspace(int64_t B, int64_t Hs, int64_t S) {
@@ -158,4 +263,29 @@ extern "C" int clipa_resized_crop_u8(const void* src, const int32_t* boxes, cons
   hipLaunchKernelGGL(rrc_vertical_kernel, dim3((unsigned)((B * S * S + 255) / 256)), dim3(256), 0, st, tmp, bounds, coef, gray_flags,
                      (unsigned char*)out, (int)B, (int)Hs, (int)S);
   return clipa_check_launch("rrc_vertical");
+}
+
+extern "C" int clipa_color_jitter_u8(void* img, const uint8_t* apply, const int32_t* order, const float* factors,
+                                     const uint8_t* gray_flags, int64_t B, int64_t S, void* workspace, int64_t workspace_bytes,
+                                     void* stream) {
+  if (B <= 0) return CLIPA_OK;
+  if (S <= 0 || S > 4096 || B * S * S / 256 + 1 > 0x7fffffffL || B > 65535) { clipa_set_error("color_jitter: bad sizes"); return CLIPA_ERR_ARG; }
+  if (order && (!factors || !workspace || workspace_bytes < B * 8)) { clipa_set_error("color_jitter: needs factors and a workspace of 8 bytes per sample"); return CLIPA_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned nblk = (unsigned)((B * S * S + 255) / 256);
+  if (order) {
+    for (int step = 0; step < 4; ++step) {
+      (void)hipMemsetAsync(workspace, 0, B * 8, st);
+      hipLaunchKernelGGL(jitter_lsum_kernel, dim3(32, (unsigned)B), dim3(256), 0, st, (const unsigned char*)img, apply, order,
+                         (unsigned long long*)workspace, (int)B, (int)S, step);
+      hipLaunchKernelGGL(jitter_step_kernel, dim3(nblk), dim3(256), 0, st, (unsigned char*)img, apply, order, factors,
+                         (const unsigned long long*)workspace, (int)B, (int)S, step);
+      if (int rc = clipa_check_launch("color_jitter")) return rc;
+    }
+  }
+  if (gray_flags) {
+    hipLaunchKernelGGL(grayscale_kernel, dim3(nblk), dim3(256), 0, st, (unsigned char*)img, gray_flags, (int)B, (int)S);
+    if (int rc = clipa_check_launch("grayscale")) return rc;
+  }
+  return CLIPA_OK;
 }

@@ -96,26 +96,54 @@ def sample_crop_boxes(batch, height, width, scale=(0.9, 1.0), ratio=(3.0 / 4.0, 
     return torch.stack([top, left, h, w], 1).to(torch.int32).contiguous()
 
 
-class DeviceAugment:
-    """RandomResizedCrop(image_size, scale, ratio, BICUBIC) [+ gray_scale(p)] of open_clip/transform.py:152-168 on a staged
-    uint8 NHWC device batch.  Returns uint8 [B, 3, S, S] in channels_last memory - the model's input format.
-    (color_jitter is not covered: batches that need it must be jittered by the loader.)"""
+def sample_color_jitter(batch, brightness, contrast, saturation, hue, prob, generator=None):
+    """Per-sample parameters of `color_jitter(brightness, contrast, saturation, hue, p)` (open_clip/transform.py:61-72 around
+    torchvision ColorJitter.get_params): apply ~ Bernoulli(prob) uint8 [B], a random permutation of the four operations
+    int32 [B,4] (0 brightness, 1 contrast, 2 saturation, 3 hue) and factors f32 [B,4] indexed by operation: U(max(0, 1 - x), 1 + x)
+    for the first three, U(-hue, hue) for the hue shift."""
+    apply = (torch.rand(batch, generator=generator) < prob).to(torch.uint8)
+    order = torch.argsort(torch.rand(batch, 4, generator=generator), dim=1).to(torch.int32).contiguous()
+    lo = torch.tensor([max(0.0, 1 - brightness), max(0.0, 1 - contrast), max(0.0, 1 - saturation), -hue])
+    hi = torch.tensor([1 + brightness, 1 + contrast, 1 + saturation, hue])
+    factors = (lo + (hi - lo) * torch.rand(batch, 4, generator=generator)).to(torch.float32).contiguous()
+    return apply, order, factors
 
-    def __init__(self, image_size, scale=(0.9, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0), gray_scale_prob=0.0, seed=0):
-        self.size, self.scale, self.ratio, self.gray_p = int(image_size), tuple(scale), tuple(ratio), float(gray_scale_prob or 0.0)
+
+class DeviceAugment:
+    """The reference's train transform (open_clip/transform.py:152-168) on a staged uint8 NHWC device batch:
+    RandomResizedCrop(image_size, scale, ratio, BICUBIC) -> [color_jitter(b, c, s, h) with probability color_jitter_prob] ->
+    [gray_scale with probability gray_scale_prob].  Returns uint8 [B, 3, S, S] in channels_last memory - the model's input
+    format.  Random parameters are sampled on the host (a few bytes per sample); the pixels never leave the device."""
+
+    def __init__(self, image_size, scale=(0.9, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0), color_jitter=None, color_jitter_prob=0.0,
+                 gray_scale_prob=0.0, seed=0):
+        self.size, self.scale, self.ratio = int(image_size), tuple(scale), tuple(ratio)
+        self.jitter = tuple(float(v) for v in color_jitter) if color_jitter else None
+        if self.jitter is not None and len(self.jitter) != 4:
+            raise ValueError("color_jitter = (brightness, contrast, saturation, hue)")
+        self.jitter_p = float(color_jitter_prob or 0.0) if self.jitter else 0.0
+        self.gray_p = float(gray_scale_prob or 0.0)
         self.gen = torch.Generator(device="cpu").manual_seed(int(seed))
+
+    def sample(self, B, Hs, Ws):
+        """-> boxes int32 [B,4], (apply, order, factors) | None, gray uint8 [B] | None: one batch's random parameters (CPU)."""
+        boxes = sample_crop_boxes(B, Hs, Ws, self.scale, self.ratio, self.gen)
+        jit = sample_color_jitter(B, *self.jitter, self.jitter_p, self.gen) if self.jitter_p > 0 else None
+        gray = (torch.rand(B, generator=self.gen) < self.gray_p).to(torch.uint8) if self.gray_p > 0 else None
+        return boxes, jit, gray
 
     def __call__(self, staged):
         from . import ops
         B, Hs, Ws, _ = staged.shape
-        boxes = sample_crop_boxes(B, Hs, Ws, self.scale, self.ratio, self.gen)
-        gray = None
-        if self.gray_p > 0:
-            gray = (torch.rand(B, generator=self.gen) < self.gray_p).to(torch.uint8)
-        if staged.is_cuda:
-            boxes = boxes.pin_memory().to(staged.device, non_blocking=True)
-            gray = gray.pin_memory().to(staged.device, non_blocking=True) if gray is not None else None
-        out = ops.resized_crop_u8(staged, boxes, self.size, gray)
+        boxes, jit, gray = self.sample(B, Hs, Ws)
+        put = (lambda t: t.pin_memory().to(staged.device, non_blocking=True)) if staged.is_cuda else (lambda t: t)
+        boxes = put(boxes)
+        gray = put(gray) if gray is not None else None
+        if jit is None:                       # grayscale rides in the resize kernel's store
+            return ops.resized_crop_u8(staged, boxes, self.size, gray).permute(0, 3, 1, 2)
+        out = ops.resized_crop_u8(staged, boxes, self.size)
+        apply, order, factors = (put(t) for t in jit)
+        ops.color_jitter_u8_(out, apply, order, factors, gray)
         return out.permute(0, 3, 1, 2)
 
 

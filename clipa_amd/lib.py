@@ -33,6 +33,7 @@ SIGNATURES = {
     "clipa_patchify": (_I32, [_P, _P, _I64, _I64, _I64, _I64, _I32, _I32, _I32, _c.POINTER(_F), _c.POINTER(_F), _P]),
     "clipa_resized_crop_workspace": (_I64, [_I64, _I64, _I64]),
     "clipa_resized_crop_u8": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _I64, _P, _P]),
+    "clipa_color_jitter_u8": (_I32, [_P, _P, _P, _P, _P, _I64, _I64, _P, _I64, _P]),
     "clipa_assemble_tokens": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
     "clipa_assemble_tokens_bwd_workspace": (_I64, [_I64, _I64, _I64]),
     "clipa_assemble_tokens_bwd": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _I64, _P]),

@@ -324,6 +324,29 @@ def resized_crop_u8(src, boxes, size, gray_flags=None):
     return out
 
 
+def color_jitter_u8_(img, apply=None, order=None, factors=None, gray_flags=None):
+    """In place on uint8 [B,S,S,3]: torchvision ColorJitter with per-sample op order (int32 [B,4] over 0 brightness, 1 contrast,
+    2 saturation, 3 hue) and factors (f32 [B,4], indexed by op) for the samples with apply[b] != 0, then Grayscale(3) of the
+    samples flagged in gray_flags - bit-exact with the Pillow code paths.  order=None: grayscale only."""
+    _chk(img, u8, "img", 4)
+    if img.shape[3] != 3 or img.shape[1] != img.shape[2] or not img.is_contiguous():
+        raise RuntimeError(f"color_jitter_u8_: img must be a contiguous uint8 [B,S,S,3] tensor, got {tuple(img.shape)}")
+    B, S = img.shape[0], img.shape[1]
+    if order is not None:
+        _chk(order, torch.int32, "order", 2)
+        _chk(factors, f32, "factors", 2)
+        if tuple(order.shape) != (B, 4) or tuple(factors.shape) != (B, 4) or not order.is_contiguous() or not factors.is_contiguous():
+            raise RuntimeError("color_jitter_u8_: order int32 [B,4] and factors f32 [B,4], contiguous")
+    for name, t in (("apply", apply), ("gray_flags", gray_flags)):
+        if t is not None:
+            _chk(t, u8, name, 1)
+            if t.numel() != B:
+                raise RuntimeError(f"color_jitter_u8_: {name} must have one byte per sample")
+    ws = torch.empty(B, device=img.device, dtype=torch.int64)
+    lib.call("clipa_color_jitter_u8", _p(img), _p(apply), _p(order), _p(factors), _p(gray_flags), B, S, _p(ws), B * 8, _stream())
+    return img
+
+
 def assemble_tokens(patch, cls, pos, B, L):
     D = patch.shape[1]
     tok = torch.empty((B * L, D), device=patch.device, dtype=bf16)

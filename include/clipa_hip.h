@@ -113,6 +113,12 @@ int clipa_patchify(const void* img, void* out, int64_t B, int64_t S, int64_t P, 
 int64_t clipa_resized_crop_workspace(int64_t B, int64_t Hs, int64_t S);
 int clipa_resized_crop_u8(const void* src, const int32_t* boxes, const uint8_t* gray_flags, void* out, int64_t B, int64_t Hs,
                           int64_t Ws, int64_t S, void* workspace, int64_t workspace_bytes, int32_t* err_count, void* stream);
+/* torchvision ColorJitter (per-sample op order[b][0..3] over {0 brightness, 1 contrast, 2 saturation, 3 hue}, factors[b][op];
+ * samples with apply[b] == 0 are left alone; order == NULL skips the jitter) followed by Grayscale(3) of the samples flagged in
+ * gray_flags (NULL: none), IN PLACE on uint8 [B,S,S,3] - the color_jitter / gray_scale stages of open_clip/transform.py:61-84,
+ * 160-168, bit-exact with the Pillow code they run on PIL images.  workspace: 8 bytes per sample. */
+int clipa_color_jitter_u8(void* img, const uint8_t* apply, const int32_t* order, const float* factors, const uint8_t* gray_flags,
+                          int64_t B, int64_t S, void* workspace, int64_t workspace_bytes, void* stream);
 /* cat(class_embedding) + positional_embedding (transformer.py:496-499) and its gradient. */
 int clipa_assemble_tokens(const void* patch, const float* cls, const float* pos, void* tokens, int64_t B,
                           int64_t L, int64_t D, void* stream);

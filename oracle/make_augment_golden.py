@@ -33,6 +33,43 @@ def main():
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "resized_crop_pil.npz"), images=imgs, boxes=boxes, gray=gray,
                         pillow_version=np.array(PIL.__version__), **out)
     print("wrote resized_crop_pil.npz with Pillow", PIL.__version__)
+    color_jitter_fixture(rng)
+
+
+def color_jitter_fixture(rng):
+    """ImageEnhance / HSV paths of torchvision's ColorJitter on PIL images: every one of the 24 op orders once."""
+    import itertools
+    from PIL import ImageEnhance
+    H = W = 40
+    orders = np.array(list(itertools.permutations(range(4))), np.int32)          # 0 brightness 1 contrast 2 saturation 3 hue
+    N = len(orders)
+    imgs = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
+    imgs[1, ..., 1] = imgs[1, ..., 0]                                                # channel ties
+    imgs[2] = imgs[2, 0, 0]                                                          # flat image
+    imgs[3] = (imgs[3] // 64) * 64                                                   # few levels
+    factors = np.stack([rng.uniform(0.68, 1.32, N), rng.uniform(0.68, 1.32, N), rng.uniform(0.68, 1.32, N),
+                        rng.uniform(-0.08, 0.08, N)], 1).astype(np.float32)
+    factors[4, :3] = 1.0
+    factors[5] = (0.0, 0.0, 0.0, 0.0)
+    out = np.zeros_like(imgs)
+    for i in range(N):
+        im = Image.fromarray(imgs[i])
+        for op in orders[i]:
+            f = float(factors[i, op])
+            if op == 0:
+                im = ImageEnhance.Brightness(im).enhance(f)
+            elif op == 1:
+                im = ImageEnhance.Contrast(im).enhance(f)
+            elif op == 2:
+                im = ImageEnhance.Color(im).enhance(f)
+            else:                                                                    # torchvision F.adjust_hue
+                h, s, v = im.convert("HSV").split()
+                np_h = (np.array(h, dtype=np.uint8).astype(np.int32) + (int(f * 255) & 0xFF)).astype(np.uint8)
+                im = Image.merge("HSV", (Image.fromarray(np_h, "L"), s, v)).convert("RGB")
+        out[i] = np.asarray(im)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "color_jitter_pil.npz"), images=imgs, orders=orders, factors=factors,
+                        jittered=out, pillow_version=np.array(PIL.__version__))
+    print("wrote color_jitter_pil.npz")
 
 
 if __name__ == "__main__":

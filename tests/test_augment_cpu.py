@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from clipa_amd import data as D
+from oracle import color_oracle as C
 from oracle import resize_oracle as R
 
 from .conftest import GOLDEN
@@ -34,6 +35,43 @@ def test_resize_oracle_matches_live_pillow():
         S = int(rng.choice([24, 84, 112, w]))
         ref = np.asarray(Image.fromarray(img).crop((l, t, l + w, t + h)).resize((S, S), Image.BICUBIC))
         assert np.array_equal(R.resized_crop(img, t, l, h, w, S), ref), (trial, H, W, t, l, h, w, S)
+
+
+def test_color_oracle_matches_pillow_fixture():
+    """All 24 orders of brightness / contrast / saturation / hue, produced by Pillow's ImageEnhance and HSV conversions."""
+    z = np.load(os.path.join(GOLDEN, "color_jitter_pil.npz"))
+    for i in range(len(z["images"])):
+        got = C.color_jitter(z["images"][i], z["orders"][i], z["factors"][i])
+        assert np.array_equal(got, z["jittered"][i]), (i, z["orders"][i])
+
+
+def test_color_oracle_matches_live_pillow():
+    Image = pytest.importorskip("PIL.Image")
+    from PIL import ImageEnhance
+    rng = np.random.default_rng(5)
+    for trial in range(40):
+        img = rng.integers(0, 256, (int(rng.integers(6, 30)), int(rng.integers(6, 30)), 3), dtype=np.uint8)
+        if trial % 4 == 0:
+            img[..., 2] = img[..., 1]
+        pil = Image.fromarray(img)
+        f = float(rng.uniform(0.5, 1.5))
+        assert np.array_equal(C.adjust_brightness(img, f), np.asarray(ImageEnhance.Brightness(pil).enhance(f)))
+        assert np.array_equal(C.adjust_contrast(img, f), np.asarray(ImageEnhance.Contrast(pil).enhance(f)))
+        assert np.array_equal(C.adjust_saturation(img, f), np.asarray(ImageEnhance.Color(pil).enhance(f)))
+        assert np.array_equal(C.rgb2hsv(img), np.asarray(pil.convert("HSV")))
+        assert np.array_equal(C.hsv2rgb(img), np.asarray(Image.fromarray(img, "HSV").convert("RGB")))
+
+
+def test_color_jitter_sampler():
+    g = torch.Generator().manual_seed(0)
+    apply, order, factors = D.sample_color_jitter(5000, 0.32, 0.32, 0.32, 0.08, 0.8, g)
+    assert apply.dtype == torch.uint8 and 0.77 < apply.float().mean() < 0.83
+    assert (order.sort(1).values == torch.arange(4, dtype=torch.int32)).all()          # every row a permutation
+    first = torch.bincount(order[:, 0].long(), minlength=4).float() / 5000
+    assert (first - 0.25).abs().max() < 0.03                                           # uniformly random order
+    assert factors[:, :3].min() >= 0.68 - 1e-6 and factors[:, :3].max() <= 1.32 + 1e-6
+    assert factors[:, 3].min() >= -0.08 - 1e-6 and factors[:, 3].max() <= 0.08 + 1e-6
+    assert abs(float(factors[:, 0].mean()) - 1.0) < 0.01 and abs(float(factors[:, 3].mean())) < 0.003
 
 
 def test_crop_box_sampler():

@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from clipa_amd import data as D
+from oracle import color_oracle as C
 from oracle import resize_oracle as R
 
 from .conftest import GOLDEN
@@ -107,6 +108,60 @@ def test_device_augment_and_prefetcher():
             if bool(gray[j]):
                 ref = R.grayscale3(ref)
             assert np.array_equal(img[j].permute(1, 2, 0).cpu().numpy(), ref), (i, j)
+    ops().check_token_ids(wait=True)
+
+
+def test_color_jitter_matches_pillow_fixture():
+    z = np.load(os.path.join(GOLDEN, "color_jitter_pil.npz"))
+    img = torch.from_numpy(z["images"]).to(DEV).clone()
+    out = ops().color_jitter_u8_(img, None, torch.from_numpy(z["orders"]).to(DEV), torch.from_numpy(z["factors"]).to(DEV))
+    got = out.cpu().numpy()
+    for i in range(len(got)):
+        assert np.array_equal(got[i], z["jittered"][i]), (i, z["orders"][i], float((got[i] != z["jittered"][i]).mean()))
+
+
+def test_color_jitter_random_batch_vs_oracle():
+    B, S = 48, 56
+    g = torch.Generator().manual_seed(11)
+    img = torch.randint(0, 256, (B, S, S, 3), generator=g, dtype=torch.uint8)
+    img[1, ..., 1] = img[1, ..., 0]
+    img[2] = 200
+    img[3] = (img[3] // 32) * 32
+    apply, order, factors = D.sample_color_jitter(B, 0.32, 0.32, 0.32, 0.08, 0.8, g)
+    factors[5] = torch.tensor([1.0, 1.0, 1.0, 0.0])
+    factors[6] = torch.tensor([0.0, 2.5, 0.0, -0.5])                  # extrapolating blends, the largest hue shift
+    gray = (torch.rand(B, generator=g) < 0.3).to(torch.uint8)
+    out = ops().color_jitter_u8_(img.to(DEV).clone(), apply.to(DEV), order.to(DEV), factors.to(DEV), gray.to(DEV)).cpu().numpy()
+    for i in range(B):
+        ref = img[i].numpy()
+        if int(apply[i]):
+            ref = C.color_jitter(ref, order[i].numpy(), factors[i].numpy())
+        if int(gray[i]):
+            ref = R.grayscale3(ref)
+        assert np.array_equal(out[i], ref), (i, int(apply[i]), order[i].tolist(), factors[i].tolist(), float((out[i] != ref).mean()))
+    only_gray = ops().color_jitter_u8_(img.to(DEV).clone(), gray_flags=gray.to(DEV)).cpu().numpy()
+    for i in range(B):
+        assert np.array_equal(only_gray[i], R.grayscale3(img[i].numpy()) if int(gray[i]) else img[i].numpy())
+
+
+def test_device_augment_full_recipe():
+    """The reference GPU recipe (scripts/exp/gpu/vit_l16/i37_t8_pretrain.sh:13): scale (0.4, 1), color_jitter (0.32, 0.32, 0.32,
+    0.08) p = 0.8, gray_scale p = 0.2 - resize, jitter and grayscale composed on the device equal the oracle's composition."""
+    S, Hs = 48, 64
+    g = torch.Generator().manual_seed(2)
+    staged = torch.randint(0, 256, (16, Hs, Hs, 3), generator=g, dtype=torch.uint8)
+    kw = dict(scale=(0.4, 1.0), color_jitter=(0.32, 0.32, 0.32, 0.08), color_jitter_prob=0.8, gray_scale_prob=0.2)
+    out = D.DeviceAugment(S, seed=9, **kw)(staged.to(DEV))
+    boxes, (apply, order, factors), gray = D.DeviceAugment(S, seed=9, **kw).sample(16, Hs, Hs)     # the same random stream
+    assert out.shape == (16, 3, S, S) and out.is_contiguous(memory_format=torch.channels_last)
+    for i in range(16):
+        t, l, h, w = (int(v) for v in boxes[i])
+        ref = R.resized_crop(staged[i].numpy(), t, l, h, w, S)
+        if int(apply[i]):
+            ref = C.color_jitter(ref, order[i].numpy(), factors[i].numpy())
+        if int(gray[i]):
+            ref = R.grayscale3(ref)
+        assert np.array_equal(out[i].permute(1, 2, 0).cpu().numpy(), ref), i
     ops().check_token_ids(wait=True)
 
 
