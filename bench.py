@@ -128,6 +128,10 @@ def main():
                     help="share of the free HBM 'auto' may spend (default 0.93 single process, 0.86 with several ranks: no OOM back-off there)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shapes", action="store_true", help="also report time and TF/s per GEMM / attention shape (stderr)")
+    ap.add_argument("--accum-freq", type=int, default=1,
+                    help="the reference's --accum-freq (train.py:216-256): the local batch is processed as this many micro-batches "
+                         "with the feature-cache procedure (no-grad forward of all, then forward+backward of each against the "
+                         "cached features of the others): one extra forward per pair buys a local batch that does not fit at once")
     ap.add_argument("--optimizer", default="adamw", choices=["adamw", "sharded"],
                     help="adamw = the reference's arrangement (DDP gradient all-reduce + a full fused AdamW per rank); sharded = "
                          "clipa_amd.zero.ShardedAdamW (gradient reduce-scatter, optimizer state / W, parameter all-gather; no DDP wrapper)")
@@ -193,11 +197,33 @@ def main():
     # uint8 NHWC (channels_last) images + int64 token ids, resident in HBM before the timed region
     images, texts = synthetic_batch(B, args.image_size, args.ctx, cfg["text_cfg"]["vocab_size"], seed=1234 + rank, device=dev)
 
+    A = max(1, args.accum_freq)
+    if B % A != 0:
+        print(f"bench.py: --batch {B} is not a multiple of --accum-freq {A}", file=sys.stderr)
+        sys.exit(2)
+
     def step(images=images, texts=texts):
         opt.zero_grad(set_to_none=True)                        # (the sharded optimizer zeroes its flat buffers instead)
-        out = step_model(images, texts)
-        loss = loss_fn(**out, output_dict=True)["contrastive_loss"]
-        loss.backward()
+        if A == 1:
+            out = step_model(images, texts)
+            loss = loss_fn(**out, output_dict=True)["contrastive_loss"]
+            loss.backward()
+        else:
+            # training/train.py:216-256: cache every micro-batch's features without grad, then re-forward each micro-batch
+            # with grad, splice its features into the cached lists, take the FULL-batch loss and back-propagate
+            chunks = list(zip(images.chunk(A), texts.chunk(A)))
+            feats = {"image_features": [], "text_features": []}
+            with torch.no_grad():
+                for im, tx in chunks:
+                    o = step_model(im, tx)
+                    for k in feats:
+                        feats[k].append(o[k])
+            for j, (im, tx) in enumerate(chunks):
+                o = step_model(im, tx)
+                scale = o.pop("logit_scale")
+                inputs = {k: torch.cat(v[:j] + [o[k]] + v[j + 1:]) for k, v in feats.items()}
+                loss = loss_fn(**inputs, logit_scale=scale, output_dict=True)["contrastive_loss"]
+                loss.backward()
         opt.step()                                             # AdamW + logit_scale clamp, multi-tensor kernels
         return loss
 
@@ -231,8 +257,8 @@ def main():
         # Spend the budget where a byte saves the most recompute FLOPs: "medium" tier first (drops LN1, in-proj,
         # attention, out-proj: ~17.5 of a block's 25.5 D^2 units for 5 D bytes per token), image tower before
         # text (wider), then upgrades medium -> "light" (the remaining 8 units for 4 more D bytes).
-        mv_b, mt_b = vt.medium_keep_bytes(B * L_img), tt.medium_keep_bytes(B * args.ctx)
-        lv_b, lt_b = vt.light_keep_bytes(B * L_img), tt.light_keep_bytes(B * args.ctx)
+        mv_b, mt_b = vt.medium_keep_bytes(B // A * L_img), tt.medium_keep_bytes(B // A * args.ctx)     # per micro-batch
+        lv_b, lt_b = vt.light_keep_bytes(B // A * L_img), tt.light_keep_bytes(B // A * args.ctx)
 
         def plan(budget):
             return plan_keep(budget, cfg["vision_cfg"]["layers"], cfg["text_cfg"]["layers"], mv_b, mt_b, lv_b, lt_b)
@@ -339,7 +365,8 @@ def main():
             "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp8" if args.precision == "fp8" else "bf16", "data": "synthetic",
             "config": {"workload": f"{args.model}@{args.image_size} + text-{args.ctx}, local batch {B}, "
-                                   f"global batch {B * world}, InfoNCE local_loss+gather_with_grad, AdamW, "
+                                   f"global batch {B * world}, " + (f"accum_freq {A} (feature cache: +1 forward per pair), " if A > 1 else "") +
+                                   f"InfoNCE local_loss+gather_with_grad, AdamW, "
                                    f"block recompute except {int(keep_v)}+{int(keep_t)} light-kept and {int(med_v)}+{int(med_t)} medium-kept (image+text) blocks", "precision": args.precision, "parallelism": f"dp{world}" + ("" if args.optimizer == "adamw" else f" zero1/{args.exchange}"),
                        "global_batch": B * world, "train_gflop_per_pair": round(gf, 2)},
             "model_flops_util": round(pairs_s / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4),

@@ -48,8 +48,18 @@ for s in $STAGES; do
     alltests)
       timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
       echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log ;;
+    smoke)
+      timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "rc=$?" >> gpurun_out/smoke.log ;;
+    pmcbench)
+      # fabric-side traffic counters over the real bench step (separate passes, counters only)
+      mkdir -p gpurun_out/pmcbench
+      for set in FETCH_SIZE WRITE_SIZE; do
+        (cd /tmp && timeout 400 rocprofv3 --pmc $set -d "$R/gpurun_out/pmcbench/$set" -o pmc -- \
+           python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --h2d-steps 0 --keep-blocks 0,0,24,4 > "$R/gpurun_out/pmcbench/$set.log" 2>&1)
+      done
+      python tools/pmc_summary.py gpurun_out/pmcbench gemm attn > gpurun_out/pmcbench_summary.txt 2>&1 ;;
     attnab)
-      timeout 300 python tools/attn_ab.py > gpurun_out/attn_ab.jsonl 2> gpurun_out/attn_ab.err ;;
+      echo "tools/attn_ab.py was removed with the experiment (profiles/r02_attention_bwd_pipelining_ab.jsonl)" ;;
     profh14)
       mkdir -p gpurun_out/prof_h14
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_h14" -o r02h14 -- \
@@ -74,5 +84,8 @@ echo "=== h14"; tail -n 2 gpurun_out/bench_h14_fp8.log 2>/dev/null | cut -c1-150
 echo "=== bench"; tail -n 3 gpurun_out/bench.log 2>/dev/null | cut -c1-3000
 echo "=== l16 fp8"; tail -n 2 gpurun_out/bench_l16_fp8.log 2>/dev/null | cut -c1-1500
 echo "=== sharded"; tail -n 3 gpurun_out/bench_sharded.log 2>/dev/null | cut -c1-1500
+echo "=== smoke"; tail -n 3 gpurun_out/smoke.log 2>/dev/null
+echo "=== prof"; head -n 16 gpurun_out/prof_kernel_stats.txt 2>/dev/null
+echo "=== pmcbench"; cat gpurun_out/pmcbench_summary.txt 2>/dev/null | head -30
 echo "=== attn ab"; cat gpurun_out/attn_ab.jsonl 2>/dev/null; tail -n 3 gpurun_out/attn_ab.err 2>/dev/null
 echo "=== prof h14"; head -n 14 gpurun_out/prof_h14_kernel_stats.txt 2>/dev/null
