@@ -116,7 +116,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_f8_kernel(F8Args p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (kt + 1 < nkt) stage((gk + 1) & 1, m0, n0, (kt + 1) * 128);
-      else if (has_next) stage((gk + 1) & 1, m1, n1, 0);
+      else {
+        if (has_next) stage((gk + 1) & 1, m1, n1, 0);
+        // the tile's 256 row scales ride the last K step as ONE 1 KiB LDS-DMA into the (idle) epilogue window: a per-lane
+        // gather of 8 scattered floats cost 64 extra wave-instructions of the CU's memory pipe per tile
+        if (p.sa && wave == 0) {
+          const __amdgpu_buffer_rsrc_t rsS = make_rsrc(p.sa + m0, (unsigned)(max(0, min(BM, p.M - m0)) * 4));
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, LDS_PTR(smem + F8_CBUF_OFF), 16, (unsigned)(lane * 16), 0, 0, 0);
+        }
+      }
       const char* sA = smem + (gk & 1) * STAGE_BYTES;
       const char* sB = sA + IMG_BYTES;
       const char* pa = sA + (wm * 128 + l15) * 128;
@@ -156,10 +164,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_f8_kernel(F8Args p) {
         sb4[bj] = (p.sb && n < p.N) ? *(const float4*)(p.sb + n) : make_float4(1.f, 1.f, 1.f, 1.f);
       }
       float sam[8];               // alpha * row scale of the 8 m blocks' row this lane holds
+      if (p.sa) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();          // the scale vector has landed in the window (pass 0 overwrites it after its own barrier)
+        const float* sc = (const float*)(smem + F8_CBUF_OFF);
 #pragma unroll
-      for (int ai = 0; ai < 8; ++ai) {
-        const int m = m0 + wm * 128 + ai * 16 + l15;
-        sam[ai] = p.alpha * ((p.sa && m < p.M) ? p.sa[m] : 1.0f);
+        for (int ai = 0; ai < 8; ++ai) sam[ai] = p.alpha * sc[wm * 128 + ai * 16 + l15];
+      } else {
+#pragma unroll
+        for (int ai = 0; ai < 8; ++ai) sam[ai] = p.alpha;
       }
       u32x4 av[8];
       auto fetch_aux = [&](int pass0) {
