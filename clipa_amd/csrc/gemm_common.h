@@ -109,6 +109,175 @@ __device__ __forceinline__ void dma16_x2(const u32x4 srd, unsigned lds_addr, uns
 }
 #define WG_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// ---------------------------------------------------------------------------------------------------------------
+// Epilogue of a 256 x 256 bf16 output tile through a 32 KiB LDS window (gemm_nt2<bf16>, gemm_nt_f8): four passes of 64
+// rows - the waves holding those rows pack them into the window (16x16 MFMA layout -> row-major, XOR-swizzled 16-byte
+// chunks), every thread then takes four 16-byte chunks, applies the element-wise epilogue and stores them.
+//
+// Every LDS access and every aux load here is inline asm, and every global store an unconditional buffer store
+// (out-of-range lanes are dropped by the descriptor): with an LDS-DMA in flight hipcc puts `s_waitcnt vmcnt(0)` in front
+// of each LDS access and each use of a loaded register it can see, and a store inside a divergent branch makes its
+// counter bookkeeping pessimistic - each of those waits drained the stores of the pass before (five round trips to HBM
+// per tile, 9.5 us of a 35 us tile at K = 1024).  Counted by hand instead; loads and stores retire in issue order on the
+// vector-memory counter.  Per wave and tile:
+//   [next tile's first K step: 8 LDS-DMA]  [aux: 8 loads per 2 passes]  [stores: 4 (8 with PRE) per pass]
+// so chunk j's aux load is always followed by 7 younger operations ((7 - k) loads + k stores), and after the last pass
+// exactly WIN_STORES(PRE) stores are younger than the next tile's operands.
+struct WinOut {
+  char* C; char* C2; const char* aux;     // C2: pre-activation copy (PRE)
+  long ldc, ldaux;
+  int M, N, m0, n0;                        // matrix extent, tile origin
+  int act, abl;
+};
+constexpr int win_stores(bool pre) { return pre ? 32 : 16; }
+
+// prepare(pass): the packing waves load what pack(ai, bj) needs for this pass (bias / scale vectors parked in LDS: held in
+// registers across the passes they would push the aux epilogues into scratch, whose loads and stores would break the counts).
+// ROLL: aux chunks in 16 registers instead of 32 - chunk j's register is refilled for the next pass right after its use
+// (gemm_nt_f8, whose scale arithmetic needs the other 16).
+template <int EPI, bool PRE, bool ROLL, typename Prepare, typename Pack>
+__device__ __forceinline__ void window_epilogue(char* cb, const WinOut& o, int tid, int wm, int wn, Prepare&& prepare, Pack&& pack) {
+  constexpr bool HAS_AUX = EPI == CLIPA_EPI_ADD || EPI == CLIPA_EPI_DACT;
+  static_assert(!(PRE && HAS_AUX), "the pre-activation copy goes with the activation epilogue");
+  // address arithmetic is redone per tile from an opaque copy of the thread id: hoisted out of the persistent tile loop
+  // it would sit in ~40 registers across the main loop
+  int tid_e = tid;
+  asm volatile("" : "+v"(tid_e));
+  const int lane_e = tid_e & 63, g4 = lane_e >> 4, l15 = lane_e & 15;
+  // output descriptors: rows past M and (by the offset's top bit) columns past N fall outside and are dropped
+  const int rows_t = min(BM, o.M - o.m0), cols_t = min(BN, o.N - o.n0);
+  const unsigned c_bytes = (unsigned)(((size_t)(rows_t - 1) * o.ldc + cols_t) * 2);
+  const __amdgpu_buffer_rsrc_t rsC = make_rsrc(o.C + ((size_t)o.m0 * o.ldc + o.n0) * 2, c_bytes);
+  const __amdgpu_buffer_rsrc_t rsC2 = make_rsrc(PRE ? o.C2 + ((size_t)o.m0 * o.ldc + o.n0) * 2 : o.C, PRE ? c_bytes : 0u);
+  // this thread's chunks of a pass: chunk c = j*512 + tid -> row c>>5 (0..63), 16-B column c&31.
+  // aux (residual / pre-activation) chunks are fetched two passes at a time, ahead of their use.
+  u32x4 av[ROLL ? 4 : 8];
+  auto fetch_one = [&](u32x4& dst, int pass, int j) {
+    const int c = j * NTHREADS + tid_e;
+    // clamped inside the matrix: the value of an out-of-range chunk is never stored
+    const int m = min(o.m0 + pass * 64 + (c >> 5), o.M - 1), n = min(o.n0 + (c & 31) * 8, o.N - 8);
+    const char* ap = o.aux + ((size_t)m * o.ldaux + n) * 2;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ap) : "memory");
+  };
+  auto fetch_aux = [&](int pass0) {
+    if constexpr (HAS_AUX) {
+#pragma unroll
+      for (int i = 0; i < (ROLL ? 4 : 8); ++i) fetch_one(av[i], pass0 + (i >> 2), i & 3);
+    }
+  };
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    if (ROLL ? pass == 0 : (pass & 1) == 0) fetch_aux(pass);
+    WG_BARRIER_LDS();   // readers of the previous pass (pass 0: of the bias / scale vectors) are done with the window
+    if (wm == (pass >> 1)) {
+      prepare(pass);
+      // 16x16 blocks: lane holds features nl..nl+3 (nl = 16 bj + 4 (lane>>4)) of row 16 a2 + (lane & 15)
+#pragma unroll
+      for (int a2 = 0; a2 < 4; ++a2) {
+        const int ai = 4 * (pass & 1) + a2;
+        const int row = a2 * 16 + l15;
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj) {
+          const int nl = wn * 64 + bj * 16 + 4 * g4;
+          const u32x2 w = pack(ai, bj);
+          const unsigned wa = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(cb + row * 512 + ((((nl >> 3) ^ row) & 31) << 4) + (nl & 7) * 2);
+          asm volatile("ds_write_b64 %0, %1" :: "v"(wa), "v"(w) : "memory");
+        }
+      }
+    }
+    WG_BARRIER_LDS();
+    // the activation-backward epilogue takes the window two chunks at a time (8 fewer live registers: no scratch)
+    constexpr int CG = EPI == CLIPA_EPI_DACT ? 2 : 4;
+#pragma unroll
+    for (int g = 0; g < 4 / CG; ++g) {
+      u32x4 cv[CG];
+      unsigned a[CG];
+#pragma unroll
+      for (int jj = 0; jj < CG; ++jj) {
+        const int c = (g * CG + jj) * NTHREADS + tid_e;
+        const int row = c >> 5, cc = c & 31;
+        a[jj] = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(cb + row * 512 + (((cc ^ row) & 31) << 4));
+      }
+      if constexpr (CG == 4)
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(cv[0]), "=&v"(cv[1]), "=&v"(cv[CG - 2]), "=&v"(cv[CG - 1])
+                     : "v"(a[0]), "v"(a[1]), "v"(a[CG - 2]), "v"(a[CG - 1])
+                     : "memory");
+      else
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(cv[0]), "=&v"(cv[1])
+                     : "v"(a[0]), "v"(a[1])
+                     : "memory");
+#pragma unroll
+      for (int jj = 0; jj < CG; ++jj) {
+        const int j = g * CG + jj;
+        const int c = j * NTHREADS + tid_e;
+        const int row = c >> 5, cc = c & 31;
+        unsigned vo = (unsigned)(((size_t)(pass * 64 + row) * o.ldc + cc * 8) * 2);
+        if (cc * 8 >= cols_t || ((o.abl & 1) && cv[jj][0] != 0x12345u)) vo |= 0x80000000u;
+        u32x4 v = cv[jj];
+        if constexpr (PRE) __builtin_amdgcn_raw_buffer_store_b128(v, rsC2, (int)vo, 0, 0);
+        if constexpr (EPI != CLIPA_EPI_NONE) {
+          u32x4& aj = av[ROLL ? j : (pass & 1) * 4 + j];
+          // operations younger than chunk j's aux load.  Batches of 8: (7 - k) loads + k stores = 7 whatever the chunk.
+          // ROLL: pass 0: (3 - j) loads + j (store + refill); later: (3 - j) (store + refill) of the pass before + j
+          // (store + refill) of this one = 6, minus the j refills the last pass no longer issues.
+          if constexpr (HAS_AUX) {
+            if constexpr (!ROLL) asm volatile("s_waitcnt vmcnt(7)" : "+v"(aj) :: "memory");
+            else {
+              const int younger = pass == 0 ? 3 + j : pass == 3 ? 6 - j : 6;
+              switch (younger) {   // pass and j are unrolled constants: one case survives
+                case 3: asm volatile("s_waitcnt vmcnt(3)" : "+v"(aj) :: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" : "+v"(aj) :: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" : "+v"(aj) :: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(6)" : "+v"(aj) :: "memory"); break;
+              }
+            }
+          } else aj = u32x4{0, 0, 0, 0};
+          if (o.act == ACT_GELU_ERF) v = epi_chunk<ACT_GELU_ERF>(EPI, v, aj);
+          else if (o.act == ACT_GELU_TANH) v = epi_chunk<ACT_GELU_TANH>(EPI, v, aj);
+          else v = epi_chunk<ACT_QUICK_GELU>(EPI, v, aj);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsC, (int)vo, 0, 0);
+        if constexpr (HAS_AUX && ROLL) {
+          if (pass < 3) fetch_one(av[j], pass + 1, j);
+        }
+      }
+    }
+  }
+}
+
+// The tile's bias / scale vectors arrive in the window by LDS-DMA during the last K step; the first pass overwrites the
+// window, so the first `bytes` of it are parked in the ring slot that last K step has just finished with (free until the
+// next tile's second K step is staged).  Call after `s_waitcnt vmcnt(0)` + barrier; the epilogue's first barrier publishes it.
+__device__ __forceinline__ void park_vectors(const char* window, char* free_slot, int tid, int bytes) {
+  if (tid * 16 < bytes) {
+    const unsigned src = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(window + tid * 16);
+    const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(free_slot + tid * 16);
+    u32x4 t;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tds_write_b128 %2, %0" : "=&v"(t) : "v"(src), "v"(dst) : "memory");
+  }
+}
+__device__ __forceinline__ void lds_read4_f4(float4 (&v)[4], const char* base) {   // v[i] = 16 bytes at base + 64 i
+  const unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)base;
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
+               "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(a) : "memory");
+}
+__device__ __forceinline__ void lds_read4_f1(float (&v)[4], const char* base) {    // v[i] = 4 bytes at base + 64 i
+  const unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)base;
+  asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:64\n\tds_read_b32 %2, %4 offset:128\n\t"
+               "ds_read_b32 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(a) : "memory");
+}
+
+// Ring protocol shared by the persistent NT kernels: a K step's operands are waited for (vmcnt + barrier) at the END of the
+// step before it, so the wait in front of a tile's first step sits after the previous tile's epilogue and can leave that
+// epilogue's stores in flight (RING_WAIT_AFTER_EPILOGUE: the 8 LDS-DMA of the step are older than the stores).
+#define RING_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define RING_WAIT_AFTER_EPILOGUE(NSTORES) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NSTORES) : "memory")
+
 // Per-device launch state: LDS opt-in attributes are set once per device (std::call_once), the CU count is read
 // from the device the call runs on.  No process-wide mutable state besides the experiment knobs (atomics).
 int gemm_num_cu(int dev);                 // multiProcessorCount of `dev`, cached

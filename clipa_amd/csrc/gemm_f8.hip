@@ -42,7 +42,8 @@ __device__ __forceinline__ i32x8 frag8(const char* rowp, int g4, int sw16) {
 }
 
 // FMT_A / FMT_B: 0 = e4m3, 1 = e5m2 of the A (activation / gradient) and B (weight) operand
-template <int FMT_A, int FMT_B>
+// EPI / PRE: compile-time epilogue selector and "also store the pre-activation" (see window_epilogue in gemm_common.h)
+template <int FMT_A, int FMT_B, int EPI, bool PRE>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_f8_kernel(F8Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -60,16 +61,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_f8_kernel(F8Args p) {
   const unsigned base = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
   const unsigned len = q8 + (xcd < r8 ? 1u : 0u);
 
-  unsigned voffA[4], voffB[4];
-  int kel[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (j * 8 + wave) * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    voffA[j] = (unsigned)(row * p.lda + chunk * 16);
-    voffB[j] = (unsigned)(row * p.ldb + chunk * 16);
-    kel[j] = chunk * 16;
-  }
+  // LEAN (activation-backward epilogue, the register-tightest instantiation): the 12 per-lane DMA offsets are recomputed
+  // at every stage() from an opaque copy of the lane id instead of living in registers across the tile loop
+  constexpr bool LEAN = EPI == CLIPA_EPI_DACT;
   const int nkt = (p.K + 127) / 128;
 
   auto tile_origin = [&](unsigned t, int& m0, int& n0) {
@@ -86,12 +80,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_f8_kernel(F8Args p) {
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B + (size_t)n0 * p.ldb, (unsigned)(min(BN, p.N - n0) * p.ldb));
     char* sA = smem + buf * STAGE_BYTES;
     char* sB = sA + IMG_BYTES;
+    int l = lane;
+    if constexpr (LEAN) asm volatile("" : "+v"(l));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int pc = j * 8 + wave;
-      const unsigned oob = (k0 + kel[j] >= p.K) ? 0x80000000u : 0u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(sA + pc * 1024), 16, voffA[j] | oob, k0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(sB + pc * 1024), 16, voffB[j] | oob, k0, 0, 0);
+      const int row = pc * 8 + (l >> 3);
+      const int chunk = (l & 7) ^ ((row >> 1) & 7);
+      const unsigned oob = (k0 + chunk * 16 >= p.K) ? 0x80000000u : 0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(sA + pc * 1024), 16, (unsigned)(row * p.lda + chunk * 16) | oob, k0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(sB + pc * 1024), 16, (unsigned)(row * p.ldb + chunk * 16) | oob, k0, 0, 0);
     }
   };
 
@@ -101,6 +99,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_f8_kernel(F8Args p) {
   tile_origin(base + it, m0, n0);
   stage(0, m0, n0, 0);
   unsigned gk = 0;
+  RING_WAIT_ALL();
   for (;;) {
     const bool has_next = it + gx < len;
     int m1 = 0, n1 = 0;
@@ -113,17 +112,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_f8_kernel(F8Args p) {
       for (int ai = 0; ai < 8; ++ai) acc16[bj][ai] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
     for (int kt = 0; kt < nkt; ++kt, ++gk) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
       if (kt + 1 < nkt) stage((gk + 1) & 1, m0, n0, (kt + 1) * 128);
       else {
-        if (has_next) stage((gk + 1) & 1, m1, n1, 0);
-        // the tile's 256 row scales ride the last K step as ONE 1 KiB LDS-DMA into the (idle) epilogue window: a per-lane
-        // gather of 8 scattered floats cost 64 extra wave-instructions of the CU's memory pipe per tile
-        if (p.sa && wave == 0) {
-          const __amdgpu_buffer_rsrc_t rsS = make_rsrc(p.sa + m0, (unsigned)(max(0, min(BM, p.M - m0)) * 4));
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, LDS_PTR(smem + F8_CBUF_OFF), 16, (unsigned)(lane * 16), 0, 0, 0);
+        // the tile's row scales, bias and column scales (256 floats each) ride the last K step as three 1 KiB LDS-DMA
+        // into the (idle) epilogue window, one per wave 0..2, issued ahead of the next tile's operands
+        const float* vsrc = wave == 0 ? p.sa : wave == 1 ? p.bias : wave == 2 ? p.sb : nullptr;
+        if (vsrc) {
+          const int o0 = wave == 0 ? m0 : n0, ext = wave == 0 ? p.M : p.N;
+          const __amdgpu_buffer_rsrc_t rsV = make_rsrc(vsrc + o0, (unsigned)(max(0, min(256, ext - o0)) * 4));
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, LDS_PTR(smem + F8_CBUF_OFF + wave * 1024), 16, (unsigned)(lane * 16), 0, 0, 0);
         }
+        if (has_next) stage((gk + 1) & 1, m1, n1, 0);
       }
       const char* sA = smem + (gk & 1) * STAGE_BYTES;
       const char* sB = sA + IMG_BYTES;
@@ -143,6 +142,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_f8_kernel(F8Args p) {
           acc16[bj][u] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(gb[bj], ga[u & 1], acc16[bj][u], FMT_B, FMT_A, 0, 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
       }
+      if (kt + 1 < nkt) RING_WAIT_ALL();
     }
 
     // ---- epilogue of tile (m0, n0); the ring keeps filling for the next tile meanwhile ----
@@ -155,94 +155,41 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_f8_kernel(F8Args p) {
       if (t == 1.2345e-30f) ((float*)p.C)[tid] = t;
     } else {
       char* cb = smem + F8_CBUF_OFF;
-      const int epi = p.epi, act = p.act;
+      // the tile's vectors (row scales | bias | column scales, 1 KiB each; out-of-range entries were DMA'd as zeros and are
+      // never stored) are parked in the ring slot the last K step has finished with and read back by the packing waves
+      char* park = smem + ((gk + 1) & 1) * STAGE_BYTES;   // gk & 1 holds the next tile's first K step
+      if (p.sa || p.bias || p.sb) {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        park_vectors(cb, park, tid, 3072);
+      }
       float4 bias4[4], sb4[4];    // the 4 consecutive features of n block bj this lane holds
+      float sam[4];               // alpha * row scale of the pass's 4 m blocks' row this lane holds
+      WinOut o;
+      o.C = p.C; o.C2 = p.C2; o.aux = p.aux; o.ldc = p.ldc; o.ldaux = p.ldaux;
+      o.M = p.M; o.N = p.N; o.m0 = m0; o.n0 = n0; o.act = p.act; o.abl = p.abl;
+      window_epilogue<EPI, PRE, true>(cb, o, tid, wm, wn,
+        [&](int pass) {
+          if (p.sa) lds_read4_f1(sam, park + (wm * 128 + (pass & 1) * 64 + l15) * 4);
+          if (p.bias) lds_read4_f4(bias4, park + 1024 + (wn * 64 + 4 * g4) * 4);
+          if (p.sb) lds_read4_f4(sb4, park + 2048 + (wn * 64 + 4 * g4) * 4);
 #pragma unroll
-      for (int bj = 0; bj < 4; ++bj) {
-        const int n = n0 + wn * 64 + bj * 16 + 4 * g4;
-        bias4[bj] = (p.bias && n < p.N) ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-        sb4[bj] = (p.sb && n < p.N) ? *(const float4*)(p.sb + n) : make_float4(1.f, 1.f, 1.f, 1.f);
-      }
-      float sam[8];               // alpha * row scale of the 8 m blocks' row this lane holds
-      if (p.sa) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();          // the scale vector has landed in the window (pass 0 overwrites it after its own barrier)
-        const float* sc = (const float*)(smem + F8_CBUF_OFF);
-#pragma unroll
-        for (int ai = 0; ai < 8; ++ai) sam[ai] = p.alpha * sc[wm * 128 + ai * 16 + l15];
-      } else {
-#pragma unroll
-        for (int ai = 0; ai < 8; ++ai) sam[ai] = p.alpha;
-      }
-      u32x4 av[8];
-      auto fetch_aux = [&](int pass0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          av[i] = u32x4{0, 0, 0, 0};
-          const int c = (i & 3) * NTHREADS + tid;
-          const int m = m0 + (pass0 + (i >> 2)) * 64 + (c >> 5), n = n0 + (c & 31) * 8;
-          if ((epi == CLIPA_EPI_ADD || epi == CLIPA_EPI_DACT) && m < p.M && n < p.N)
-            av[i] = *(const u32x4*)(p.aux + ((size_t)m * p.ldaux + n) * 2);
-        }
-      };
-#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        if ((pass & 1) == 0) fetch_aux(pass);
-        LDS_BARRIER();   // readers of the previous pass are done with the window
-        if (wm == (pass >> 1)) {
-#pragma unroll
-          for (int a2 = 0; a2 < 4; ++a2) {
-            const int ai = 4 * (pass & 1) + a2;
-            const int row = a2 * 16 + l15;
-            const float s = sam[ai];
-#pragma unroll
-            for (int bj = 0; bj < 4; ++bj) {
-              const int nl = wn * 64 + bj * 16 + 4 * g4;
-              const float4 b4 = bias4[bj], q4 = sb4[bj];
-              u32x2 w;
-              w[0] = pack2bf(acc16[bj][ai][0] * (s * q4.x) + b4.x, acc16[bj][ai][1] * (s * q4.y) + b4.y);
-              w[1] = pack2bf(acc16[bj][ai][2] * (s * q4.z) + b4.z, acc16[bj][ai][3] * (s * q4.w) + b4.w);
-              *(u32x2*)(cb + row * 512 + ((((nl >> 3) ^ row) & 31) << 4) + (nl & 7) * 2) = w;
-            }
+          for (int i = 0; i < 4; ++i) {
+            sam[i] = p.sa ? sam[i] * p.alpha : p.alpha;
+            if (!p.bias) bias4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!p.sb) sb4[i] = make_float4(1.f, 1.f, 1.f, 1.f);
           }
-        }
-        LDS_BARRIER();
-        u32x4 cv[4];
-        {
-          unsigned a[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int c = j * NTHREADS + tid;
-            const int row = c >> 5, cc = c & 31;
-            a[j] = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(cb + row * 512 + (((cc ^ row) & 31) << 4));
-          }
-          asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\t"
-                       "s_waitcnt lgkmcnt(0)"
-                       : "=&v"(cv[0]), "=&v"(cv[1]), "=&v"(cv[2]), "=&v"(cv[3])
-                       : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3])
-                       : "memory");
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int c = j * NTHREADS + tid;
-          const int row = c >> 5, cc = c & 31;
-          const int m = m0 + pass * 64 + row, n = n0 + cc * 8;
-          if (m < p.M && n < p.N) {
-            u32x4 v = cv[j];
-            if (epi == CLIPA_EPI_ACT && p.C2) *(u32x4*)(p.C2 + ((size_t)m * p.ldc + n) * 2) = v;
-            if (epi != CLIPA_EPI_NONE) {
-              if (act == ACT_GELU_ERF) v = epi_chunk<ACT_GELU_ERF>(epi, v, av[(pass & 1) * 4 + j]);
-              else if (act == ACT_GELU_TANH) v = epi_chunk<ACT_GELU_TANH>(epi, v, av[(pass & 1) * 4 + j]);
-              else v = epi_chunk<ACT_QUICK_GELU>(epi, v, av[(pass & 1) * 4 + j]);
-            }
-            *(u32x4*)(p.C + ((size_t)m * p.ldc + n) * 2) = v;
-          }
-        }
-      }
-#undef LDS_BARRIER
+        },
+        [&](int ai, int bj) {
+          const float s = sam[ai & 3];
+          const float4 b4 = bias4[bj], q4 = sb4[bj];
+          u32x2 w;
+          w[0] = pack2bf(acc16[bj][ai][0] * (s * q4.x) + b4.x, acc16[bj][ai][1] * (s * q4.y) + b4.y);
+          w[1] = pack2bf(acc16[bj][ai][2] * (s * q4.z) + b4.z, acc16[bj][ai][3] * (s * q4.w) + b4.w);
+          return w;
+        });
     }
     if (!has_next) break;
+    RING_WAIT_AFTER_EPILOGUE(win_stores(PRE));   // the next tile's first K step has landed; this tile's stores need not have
     it += gx;
     m0 = m1;
     n0 = n1;
@@ -255,9 +202,12 @@ int g_f8_rc[MAX_DEVICES];
 int ensure_f8_attrs(int dev) {
   std::call_once(g_f8_once[dev], [dev]() {
     int rc = 0;
-    const void* ks[4] = {(const void*)gemm_nt_f8_kernel<0, 0>, (const void*)gemm_nt_f8_kernel<1, 0>,
-                         (const void*)gemm_nt_f8_kernel<0, 1>, (const void*)gemm_nt_f8_kernel<1, 1>};
-    for (int i = 0; i < 4; ++i) {
+#define F8_KS(E, P2) (const void*)gemm_nt_f8_kernel<0, 0, E, P2>, (const void*)gemm_nt_f8_kernel<1, 0, E, P2>, \
+                     (const void*)gemm_nt_f8_kernel<0, 1, E, P2>, (const void*)gemm_nt_f8_kernel<1, 1, E, P2>
+    const void* ks[20] = {F8_KS(CLIPA_EPI_NONE, false), F8_KS(CLIPA_EPI_ACT, false), F8_KS(CLIPA_EPI_ACT, true),
+                          F8_KS(CLIPA_EPI_ADD, false), F8_KS(CLIPA_EPI_DACT, false)};
+#undef F8_KS
+    for (int i = 0; i < 20; ++i) {
       const hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS_BYTES);
       if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_nt_f8): %s", hipGetErrorString(e)); rc = CLIPA_ERR_LAUNCH; }
     }
@@ -296,9 +246,18 @@ extern "C" int clipa_gemm_nt_f8(const void* A8, const void* B8, const float* sca
   hipStream_t st = (hipStream_t)stream;
   const long tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   const dim3 grid((unsigned)(tiles < num_cu ? tiles : num_cu)), block(NTHREADS);
-  if (fmt_a == 0 && fmt_b == 0) hipLaunchKernelGGL((gemm_nt_f8_kernel<0, 0>), grid, block, F8_LDS_BYTES, st, a);
-  else if (fmt_a == 1 && fmt_b == 0) hipLaunchKernelGGL((gemm_nt_f8_kernel<1, 0>), grid, block, F8_LDS_BYTES, st, a);
-  else if (fmt_a == 0 && fmt_b == 1) hipLaunchKernelGGL((gemm_nt_f8_kernel<0, 1>), grid, block, F8_LDS_BYTES, st, a);
-  else hipLaunchKernelGGL((gemm_nt_f8_kernel<1, 1>), grid, block, F8_LDS_BYTES, st, a);
+#define LAUNCH_F8(E, P2)                                                                                                   \
+  do {                                                                                                                     \
+    if (fmt_a == 0 && fmt_b == 0) hipLaunchKernelGGL((gemm_nt_f8_kernel<0, 0, E, P2>), grid, block, F8_LDS_BYTES, st, a);      \
+    else if (fmt_a == 1 && fmt_b == 0) hipLaunchKernelGGL((gemm_nt_f8_kernel<1, 0, E, P2>), grid, block, F8_LDS_BYTES, st, a); \
+    else if (fmt_a == 0 && fmt_b == 1) hipLaunchKernelGGL((gemm_nt_f8_kernel<0, 1, E, P2>), grid, block, F8_LDS_BYTES, st, a); \
+    else hipLaunchKernelGGL((gemm_nt_f8_kernel<1, 1, E, P2>), grid, block, F8_LDS_BYTES, st, a);                               \
+  } while (0)
+  if (epi == CLIPA_EPI_NONE) LAUNCH_F8(CLIPA_EPI_NONE, false);
+  else if (epi == CLIPA_EPI_ACT && C2) LAUNCH_F8(CLIPA_EPI_ACT, true);
+  else if (epi == CLIPA_EPI_ACT) LAUNCH_F8(CLIPA_EPI_ACT, false);
+  else if (epi == CLIPA_EPI_ADD) LAUNCH_F8(CLIPA_EPI_ADD, false);
+  else LAUNCH_F8(CLIPA_EPI_DACT, false);
+#undef LAUNCH_F8
   return clipa_check_launch("gemm_nt_f8");
 }

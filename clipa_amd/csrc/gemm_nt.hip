@@ -34,7 +34,11 @@ constexpr int LDS2_BYTES = CBUF_OFF + 64 * 512;      // 163840 = all 160 KiB of 
 // blocks of 16 x 16, fragment = 16 rows x 32 k: lane -> row l&15, chunk 4*kk + (l>>4); the image and its
 // (row>>1)&7 swizzle are unchanged and stay conflict-free for that read).  A quarter of the accumulator registers
 // are read and written per instruction: less register-file energy per FLOP, which is what counts under the power cap.
-template <bool OUT_F32, bool SETPRIO, bool M16 = false>
+// EPI / PRE (bf16 output): the epilogue and "also store the pre-activation" are compile-time, so that an epilogue without aux
+// operand holds no aux registers and the compiler's vmcnt bookkeeping sees one straight-line sequence of loads and stores:
+// with a run-time epilogue selector it has to place `s_waitcnt vmcnt(0)` in front of every chunk (the aux registers are
+// written on one path and overwritten on another), which drains the chunk's predecessor store before the next one issues.
+template <bool OUT_F32, bool SETPRIO, bool M16 = false, int EPI = CLIPA_EPI_NONE, bool PRE = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
   static_assert(!M16 || !OUT_F32, "16x16x32 variant: bf16 output");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -101,7 +105,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
   int m0, n0;
   tile_origin(base + it, m0, n0);
   stage(0, m0, n0, 0);
-  unsigned gk = 0;   // global K-tile (STAG: phase) counter: ring slot = gk & 1 (STAG: gk & 3)
+  unsigned gk = 0;   // global K-tile counter: ring slot = gk & 1
+  RING_WAIT_ALL();
   for (;;) {
     const bool has_next = it + gx < len;
     int m1 = 0, n1 = 0;
@@ -124,10 +129,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
     }
 
     for (int kt = 0; kt < nkt; ++kt, ++gk) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
       if (kt + 1 < nkt) stage((gk + 1) & 1, m0, n0, (kt + 1) * BK);
-      else if (has_next) stage((gk + 1) & 1, m1, n1, 0);
+      else {
+        // the tile's 256 bias values ride the last K step as ONE 1 KiB LDS-DMA into the (idle) epilogue window
+        if (!OUT_F32 && p.bias && wave == 0) {
+          const __amdgpu_buffer_rsrc_t rsBias = make_rsrc(p.bias + n0, (unsigned)(max(0, min(BN, p.N - n0)) * 4));
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBias, LDS_PTR(smem + CBUF_OFF), 16, (unsigned)(lane * 16), 0, 0, 0);
+        }
+        if (has_next) stage((gk + 1) & 1, m1, n1, 0);
+      }
       const char* sA = smem + (gk & 1) * STAGE_BYTES;
       const char* sB = sA + IMG_BYTES;
       if constexpr (M16) {
@@ -161,6 +171,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
               acc16[bj][2 * sb + a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gb[kk][bj], ga[u & 1][a], acc16[bj][2 * sb + a], 0, 0, 0);
           if (SETPRIO) __builtin_amdgcn_s_setprio(0);
         }
+        if (kt + 1 < nkt) RING_WAIT_ALL();
         continue;
       }
       bf16x8 fa[2][4], fb[2][2];
@@ -186,6 +197,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
             acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][ni], fa[cur][mi], acc[ni][mi], 0, 0, 0);
         if (SETPRIO) __builtin_amdgcn_s_setprio(0);
       }
+      if (kt + 1 < nkt) RING_WAIT_ALL();
     }
 
     // ---- epilogue of tile (m0, n0); the ring keeps filling for the next tile meanwhile ----
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
             for (int r = 0; r < 16; ++r) t += acc[ni][mi][r];
       }
       if (t == 1.2345e-30f) ((float*)p.C)[tid] = t;
-    } else if (OUT_F32) {
+    } else if constexpr (OUT_F32) {
       float* C = (float*)p.C;
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
@@ -228,109 +240,40 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
           }
         }
     } else {
+      static_assert(M16 || OUT_F32, "bf16 output: 16x16x32 main loop only");
       char* cb = smem + CBUF_OFF;
-      const int epi = p.epi, act = p.act;
-      float4 bias4[2][4];     // M16 uses [0][bj]: the 4 consecutive features of n block bj this lane holds
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (M16 && ni == 1) continue;
-          const int n = M16 ? n0 + wn * 64 + q * 16 + 4 * (lane >> 4) : n0 + wn * 64 + ni * 32 + 8 * q + 4 * hi;
-          bias4[ni][q] = (p.bias && n < p.N && !(p.abl & 4)) ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      // this thread's chunks of a pass: chunk c = j*512 + tid -> row c>>5 (0..63), 16-B column c&31.
-      // aux (residual / pre-activation) chunks are fetched two passes at a time, ahead of their use.
-      u32x4 av[8];
-      auto fetch_aux = [&](int pass0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          av[i] = u32x4{0, 0, 0, 0};
-          const int c = (i & 3) * NTHREADS + tid;
-          const int m = m0 + (pass0 + (i >> 2)) * 64 + (c >> 5), n = n0 + (c & 31) * 8;
-          if ((epi == CLIPA_EPI_ADD || epi == CLIPA_EPI_DACT) && m < p.M && n < p.N)
-            av[i] = *(const u32x4*)(p.aux + ((size_t)m * p.ldaux + n) * 2);
-        }
-      };
-      // LDS-only barriers: a full __syncthreads() would also wait (vmcnt) for the previous pass's global stores
-#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        if ((pass & 1) == 0) fetch_aux(pass);
-        LDS_BARRIER();   // readers of the previous pass are done with the window
-        if (M16 && wm == (pass >> 1)) {
-          // 16x16 blocks: lane holds features nl..nl+3 (nl = 16 bj + 4 (lane>>4)) of row 16 a2 + (lane & 15)
-#pragma unroll
-          for (int a2 = 0; a2 < 4; ++a2) {
-            const int ai = 4 * (pass & 1) + a2;
-            const int row = a2 * 16 + (lane & 15);
-#pragma unroll
-            for (int bj = 0; bj < 4; ++bj) {
-              const int nl = wn * 64 + bj * 16 + 4 * (lane >> 4);
-              const float4 b4 = bias4[0][bj];
-              u32x2 w;
-              w[0] = pack2bf(acc16[bj][ai][0] * p.alpha + b4.x, acc16[bj][ai][1] * p.alpha + b4.y);
-              w[1] = pack2bf(acc16[bj][ai][2] * p.alpha + b4.z, acc16[bj][ai][3] * p.alpha + b4.w);
-              *(u32x2*)(cb + row * 512 + ((((nl >> 3) ^ row) & 31) << 4) + (nl & 7) * 2) = w;
-            }
-          }
-        } else if (wm == (pass >> 1)) {
-#pragma unroll
-          for (int mi2 = 0; mi2 < 2; ++mi2) {
-            const int mi = 2 * (pass & 1) + mi2;
-            const int row = mi2 * 32 + l31;
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const int nl = wn * 64 + ni * 32 + 8 * q + 4 * hi;
-                const float4 b4 = bias4[ni][q];
-                u32x2 w;
-                w[0] = pack2bf(acc[ni][mi][4 * q + 0] * p.alpha + b4.x, acc[ni][mi][4 * q + 1] * p.alpha + b4.y);
-                w[1] = pack2bf(acc[ni][mi][4 * q + 2] * p.alpha + b4.z, acc[ni][mi][4 * q + 3] * p.alpha + b4.w);
-                *(u32x2*)(cb + row * 512 + ((((nl >> 3) ^ row) & 31) << 4) + (nl & 7) * 2) = w;
-              }
-          }
-        }
-        LDS_BARRIER();
-        // The window is read with inline-asm ds_read_b128: with an LDS-DMA possibly in flight hipcc puts
-        // `s_waitcnt vmcnt(0)` in front of every compiler-visible LDS read, which would serialise each
-        // pass behind the global stores of the previous one.  (Hidden loads: waited for by hand, §5.7.)
-        u32x4 cv[4];
-        {
-          unsigned a[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int c = j * NTHREADS + tid;
-            const int row = c >> 5, cc = c & 31;
-            a[j] = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(cb + row * 512 + (((cc ^ row) & 31) << 4));
-          }
-          asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\t"
-                       "s_waitcnt lgkmcnt(0)"
-                       : "=&v"(cv[0]), "=&v"(cv[1]), "=&v"(cv[2]), "=&v"(cv[3])
-                       : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3])
-                       : "memory");
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int c = j * NTHREADS + tid;
-          const int row = c >> 5, cc = c & 31;
-          const int m = m0 + pass * 64 + row, n = n0 + cc * 8;
-          if (m < p.M && n < p.N && !((p.abl & 1) && cv[j][0] != 0x12345u)) {
-            u32x4 v = cv[j];
-            if (epi == CLIPA_EPI_ACT && p.C2) *(u32x4*)(p.C2 + ((size_t)m * p.ldc + n) * 2) = v;
-            if (epi != CLIPA_EPI_NONE) {
-              if (act == ACT_GELU_ERF) v = epi_chunk<ACT_GELU_ERF>(epi, v, av[(pass & 1) * 4 + j]);
-              else if (act == ACT_GELU_TANH) v = epi_chunk<ACT_GELU_TANH>(epi, v, av[(pass & 1) * 4 + j]);
-              else v = epi_chunk<ACT_QUICK_GELU>(epi, v, av[(pass & 1) * 4 + j]);
-            }
-            *(u32x4*)(p.C + ((size_t)m * p.ldc + n) * 2) = v;
-          }
-        }
+      // bias of this tile's 256 columns: landed in the window with the last K step (see the main loop), parked in the ring
+      // slot that step has finished with, read back by the packing waves of each pass
+      const bool use_bias = p.bias && !(p.abl & 4);
+      char* park = smem + ((gk + 1) & 1) * STAGE_BYTES;   // gk & 1 holds the next tile's first K step
+      if (use_bias) {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        park_vectors(cb, park, tid, 1024);
       }
-#undef LDS_BARRIER
+      float4 bias4[4];
+      WinOut o;
+      o.C = p.C; o.C2 = p.C2; o.aux = p.aux; o.ldc = p.ldc; o.ldaux = p.ldaux;
+      o.M = p.M; o.N = p.N; o.m0 = m0; o.n0 = n0; o.act = p.act; o.abl = p.abl;
+      window_epilogue<EPI, PRE, false>(cb, o, tid, wm, wn,
+        [&](int) {
+          if (use_bias) lds_read4_f4(bias4, park + (wn * 64 + 4 * (lane >> 4)) * 4);
+          else {
+#pragma unroll
+            for (int bj = 0; bj < 4; ++bj) bias4[bj] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        },
+        [&](int ai, int bj) {
+          const float4 b4 = bias4[bj];
+          u32x2 w;
+          w[0] = pack2bf(acc16[bj][ai][0] * p.alpha + b4.x, acc16[bj][ai][1] * p.alpha + b4.y);
+          w[1] = pack2bf(acc16[bj][ai][2] * p.alpha + b4.z, acc16[bj][ai][3] * p.alpha + b4.w);
+          return w;
+        });
     }
     if (!has_next) break;
+    // the next tile's first K step (issued before the epilogue) has landed; the epilogue's stores need not have
+    if constexpr (OUT_F32) RING_WAIT_ALL();
+    else RING_WAIT_AFTER_EPILOGUE(win_stores(PRE));
     it += gx;
     m0 = m1;
     n0 = n1;
@@ -344,8 +287,13 @@ int g_nt_rc[MAX_DEVICES];
 int ensure_nt_attrs(int dev) {
   std::call_once(g_nt_once[dev], [dev]() {
     int rc = 0;
-    const void* v2[2] = {(const void*)gemm_nt2_kernel<true, false>, (const void*)gemm_nt2_kernel<false, true, true>};
-    for (int i = 0; i < 2; ++i) {
+    const void* v2[6] = {(const void*)gemm_nt2_kernel<true, false>,
+                         (const void*)gemm_nt2_kernel<false, true, true, CLIPA_EPI_NONE, false>,
+                         (const void*)gemm_nt2_kernel<false, true, true, CLIPA_EPI_ACT, false>,
+                         (const void*)gemm_nt2_kernel<false, true, true, CLIPA_EPI_ACT, true>,
+                         (const void*)gemm_nt2_kernel<false, true, true, CLIPA_EPI_ADD, false>,
+                         (const void*)gemm_nt2_kernel<false, true, true, CLIPA_EPI_DACT, false>};
+    for (int i = 0; i < 6; ++i) {
       const hipError_t e = hipFuncSetAttribute(v2[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES);
       if (e != hipSuccess) { clipa_set_error("hipFuncSetAttribute(gemm_nt2): %s", hipGetErrorString(e)); rc = CLIPA_ERR_LAUNCH; }
     }
@@ -414,10 +362,17 @@ extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, co
     hipLaunchKernelGGL((gemm_nt2_kernel<true, false>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
     return clipa_check_launch("gemm_nt2<f32>");
   }
-  // bf16 output: the 16x16x32 main loop with the LDS-window epilogue for every shape and epilogue.  One kernel on
-  // purpose: a block's backward-time recompute must reproduce its forward bit for bit, so the same epilogue code has
-  // to serve the one-output and the two-output (pre-activation copy) form of the activation epilogue.
+  // bf16 output: the 16x16x32 main loop with the LDS-window epilogue for every shape; one instantiation per epilogue.
+  // A block's backward-time recompute must reproduce its forward bit for bit: the one-output and the two-output
+  // (pre-activation copy) form of the activation epilogue run the same arithmetic (epi_chunk), PRE only adds a store
+  // (tests/test_kernels_gpu.py::test_recompute_equals_stored_activations).
   const unsigned grid = (unsigned)(tiles < num_cu ? tiles : num_cu);
-  hipLaunchKernelGGL((gemm_nt2_kernel<false, true, true>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a);
+#define LAUNCH_NT(E, P2) hipLaunchKernelGGL((gemm_nt2_kernel<false, true, true, E, P2>), dim3(grid), dim3(NTHREADS), LDS2_BYTES, st, a)
+  if (epi == CLIPA_EPI_NONE) LAUNCH_NT(CLIPA_EPI_NONE, false);
+  else if (epi == CLIPA_EPI_ACT && C2) LAUNCH_NT(CLIPA_EPI_ACT, true);
+  else if (epi == CLIPA_EPI_ACT) LAUNCH_NT(CLIPA_EPI_ACT, false);
+  else if (epi == CLIPA_EPI_ADD) LAUNCH_NT(CLIPA_EPI_ADD, false);
+  else LAUNCH_NT(CLIPA_EPI_DACT, false);
+#undef LAUNCH_NT
   return clipa_check_launch("gemm_nt2<bf16>");
 }
