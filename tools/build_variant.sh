@@ -1,0 +1,12 @@
+#!/bin/bash
+# Build a variant of libclipa_hip.so with extra -D flags on ONE source (A/B experiments with tools/gemm_lib_ab.py):
+#   tools/build_variant.sh NAME SOURCE.hip -DFOO=1 ...   ->  clipa_amd/lib/libclipa_var_NAME.so
+set -e
+cd "$(dirname "$0")/.."
+name=$1; src=$2; shift 2
+python -m clipa_amd.build > /dev/null
+obj=clipa_amd/lib/obj/var_${name}.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I clipa_amd/csrc -I include -Wno-unused-result -ffp-contract=fast "$@" -c clipa_amd/csrc/$src -o $obj
+others=$(ls clipa_amd/lib/obj/*.o | grep -v "/var_" | grep -v "/${src%.hip}.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o clipa_amd/lib/libclipa_var_${name}.so $obj $others
+echo clipa_amd/lib/libclipa_var_${name}.so

@@ -1,5 +1,6 @@
-"""A/B of two builds of libclipa_hip.so in ONE process (interleaved rounds, median): clipa_gemm_nt / clipa_gemm_nt_f8 per epilogue.
-    python tools/gemm_lib_ab.py clipa_amd/lib/libclipa_hip_head.so clipa_amd/lib/libclipa_hip.so [f8]"""
+"""A/B of several builds of libclipa_hip.so in ONE process (interleaved rounds, median): clipa_gemm_nt / clipa_gemm_nt_f8 per
+epilogue; the first library is the baseline.
+    python tools/gemm_lib_ab.py [f8] clipa_amd/lib/libclipa_hip.so clipa_amd/lib/libclipa_var_X.so ..."""
 import ctypes
 import json
 import os
@@ -11,8 +12,11 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from clipa_amd import ops  # noqa: E402  (quantize_rows for the fp8 operands)
 
-libs = [ctypes.CDLL(os.path.abspath(p)) for p in sys.argv[1:3]]
-f8 = len(sys.argv) > 3 and sys.argv[3] == "f8"
+argv = sys.argv[1:]
+f8 = bool(argv) and argv[0] == "f8"
+paths = argv[1:] if f8 else argv
+libs = [ctypes.CDLL(os.path.abspath(p)) for p in paths]
+NL = len(libs)
 P, I64, F, I = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int
 for L in libs:
     L.clipa_gemm_nt.argtypes = [P] * 6 + [I64] * 7 + [F, I, I, I, P]
@@ -43,13 +47,13 @@ for N, K in ((4096, 1024), (1024, 4096), (1024, 1024), (3072, 1024)):
             else:
                 rc = L.clipa_gemm_nt(a.data_ptr(), b.data_ptr(), out[i].data_ptr(), pp, bp, ap, M, N, K, K, K, N, N if use_aux else 0, 1.0, epi, 0, 0, st)
             assert rc == 0
-        for i in range(2):
+        for i in range(NL):
             once(i)
         torch.cuda.synchronize()
-        same = bool(torch.equal(out[0], out[1])) and (not use_pre or bool(torch.equal(pre[0], pre[1])))
-        ts = [[], []]
+        same = all(bool(torch.equal(out[0], out[i])) and (not use_pre or bool(torch.equal(pre[0], pre[i]))) for i in range(1, NL))
+        ts = [[] for _ in range(NL)]
         for _ in range(5):
-            for i in range(2):
+            for i in range(NL):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(3):
@@ -58,5 +62,5 @@ for N, K in ((4096, 1024), (1024, 4096), (1024, 1024), (3072, 1024)):
                 torch.cuda.synchronize()
                 ts[i].append(e0.elapsed_time(e1) / 3)
         tf = [2.0 * M * N * K / statistics.median(t) / 1e9 for t in ts]
-        print(json.dumps({"kernel": "gemm_nt_f8" if f8 else "gemm_nt", "N": N, "K": K, "epi": name, "A_TF": round(tf[0], 1), "B_TF": round(tf[1], 1),
-                          "B_over_A": round(tf[1] / tf[0], 3), "bit_identical": same}), flush=True)
+        print(json.dumps({"kernel": "gemm_nt_f8" if f8 else "gemm_nt", "N": N, "K": K, "epi": name, "TF": [round(t, 1) for t in tf],
+                          "vs_first": [round(t / tf[0], 3) for t in tf], "bit_identical": same}), flush=True)
