@@ -11,7 +11,7 @@ text = open(sys.argv[1]).read()
 kernels = re.findall(r"^(_Z\w+):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M)
 bad = 0
 for name, body in kernels:
-    if "global_load_dwordx4" not in body:
+    if "global_load_dwordx4" not in body and "buffer_store_dwordx4" not in body:
         continue
     queue = []          # (kind, set(dest regs))
     viol = 0
@@ -51,6 +51,13 @@ for name, body in kernels:
             nload += 1
         elif re.match(r"(buffer|global|flat)_(load|store|atomic)", t):
             queue.append(("other", set()))
+    # the wait in front of the next tile's first K step leaves exactly the epilogue's stores in flight: 16 per wave, 32 with the
+    # pre-activation copy; the epilogue may be emitted more than once (loop rotation), never partially
+    after = re.search(r"s_waitcnt vmcnt\((16|32)\) lgkmcnt\(0\)", body)
+    nstore = len(re.findall(r"^\s*buffer_store_dwordx4", body, re.M))
+    if after and (nstore == 0 or nstore % int(after.group(1)) != 0):
+        viol += 1
+        print(name[:60], f"STORE COUNT {nstore} is not a multiple of the counted {after.group(1)}")
     print(f"{name[:90]}: {nload} hidden loads, {viol} violations")
     bad += viol
 sys.exit(1 if bad else 0)
