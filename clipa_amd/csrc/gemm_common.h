@@ -21,7 +21,19 @@ struct NTArgs {
   float alpha;
   int epi, act;
   int abl;   // experiment flags (clipa_debug_set): 1 no global stores, 2 no epilogue, 8 row-major tile order
+  int gm;    // A panels per tile group (nt_group_size)
 };
+
+// Tile order of the persistent NT kernels: an XCD walks groups of `gm` A panels, N-tile major inside a group.  More panels per
+// group = fewer passes of the weight matrix through the fabric (it does not fit one XCD's 4 MiB L2 and is re-fetched once per
+// group); the group's A panels must stay cache-resident while the N tiles go by.  Measured (r02_gemm_tile_group_size_ab.jsonl):
+// 8 for wide outputs, 16 for narrow ones, capped at 8 MiB of A panels per group.
+inline int nt_group_size(long tilesN, long panel_bytes) {
+  const long want = tilesN <= 12 ? 16 : 8;
+  const long cap = (8L << 20) / (panel_bytes > 0 ? panel_bytes : 1);
+  const long g = want < cap ? want : cap;
+  return (int)(g < 2 ? 2 : g);
+}
 
 struct TNArgs {
   const char* P; const char* Q; float* O;

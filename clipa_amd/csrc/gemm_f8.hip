@@ -30,6 +30,7 @@ struct F8Args {
   long lda, ldb, ldc, ldaux;            // element strides (A, B: bytes)
   float alpha;
   int epi, act, abl;
+  int gm;                               // A panels per tile group (nt_group_size)
 };
 
 __device__ __forceinline__ i32x8 frag8(const char* rowp, int g4, int sw16) {
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_f8_kernel(F8Args p) {
   const int nkt = (p.K + 127) / 128;
 
   auto tile_origin = [&](unsigned t, int& m0, int& n0) {
-    const int GM = 4;
+    const int GM = p.gm;
     const int per = GM * tilesN;
     const int g = (int)t / per, r = (int)t - g * per;
     const int gm = min(GM, tilesM - g * GM);
@@ -243,6 +244,7 @@ extern "C" int clipa_gemm_nt_f8(const void* A8, const void* B8, const float* sca
   a.sa = scale_a; a.sb = scale_b;
   a.M = (int)M; a.N = (int)N; a.K = (int)K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
   a.alpha = alpha; a.epi = epi; a.act = act; a.abl = g_abl.load(std::memory_order_relaxed);
+  a.gm = nt_group_size((N + BN - 1) / BN, 256L * K);
   hipStream_t st = (hipStream_t)stream;
   const long tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   const dim3 grid((unsigned)(tiles < num_cu ? tiles : num_cu)), block(NTHREADS);

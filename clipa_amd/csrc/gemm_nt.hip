@@ -74,11 +74,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt2_kernel(NTArgs p) {
   const int rowoffB = (wn * 64 + l31) * 128;
   const int nkt = (p.K + BK - 1) / BK;
 
-  // Tile order inside an XCD's range: groups of GM A-panels, N-tile major inside a group, so the ~32
-  // tiles an XCD runs concurrently touch GM A-panels x (32/GM) B-tiles instead of 2 x 16 (fewer distinct
-  // operand tiles per L2).  p.abl bit 3 selects the plain row-major order for A/B experiments.
+  // Tile order inside an XCD's range: groups of GM = p.gm A-panels (nt_group_size), N-tile major inside a group, so the
+  // ~32 tiles an XCD runs concurrently touch GM A-panels x (32/GM) B-tiles instead of 2 x 16 (fewer distinct operand tiles
+  // per L2) and the weight matrix passes through the fabric once per group.  p.abl bit 3: plain row-major order (A/B).
   auto tile_origin = [&](unsigned t, int& m0, int& n0) {
-    const int GM = (p.abl & 8) ? 1 : 4;
+    const int GM = (p.abl & 8) ? 1 : p.gm;
     const int per = GM * tilesN;
     const int g = (int)t / per, r = (int)t - g * per;
     const int gm = min(GM, tilesM - g * GM);
@@ -355,6 +355,7 @@ extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, co
   a.A = (const char*)A; a.B = (const char*)B; a.C = (char*)C; a.C2 = (char*)C2; a.bias = bias; a.aux = (const char*)aux;
   a.M = (int)M; a.N = (int)N; a.K = (int)K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
   a.alpha = alpha; a.epi = epi; a.act = act; a.abl = g_abl.load(std::memory_order_relaxed);
+  a.gm = nt_group_size((N + BN - 1) / BN, 256L * K * 2);
   hipStream_t st = (hipStream_t)stream;
   const long tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   if (out_f32) {
