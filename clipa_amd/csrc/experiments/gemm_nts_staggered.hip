@@ -1,7 +1,8 @@
 // EXPERIMENT (round 2, not linked into libclipa_hip.so): staggered-epilogue GEMM.  Correct on the first run (every epilogue
 // against fp64, one- vs two-output activation epilogue bit-equal, relaunch bit-equal: tools/nts_check_experiment.py) and
 // SLOWER than gemm_nt2_kernel on every production shape (0.57-0.82x, profiles/r02_gemm_staggered_epilogue.md).  What it
-// established: the main loop is bound by the CU's vector-memory pipe, not by the matrix pipe - 64 LDS-DMA pieces of 1 KiB
+// claimed then (RETRACTED later in the round - profiles/r02_gemm_counted_waits.md: a CU pulls 67 B/clk through LDS-DMA from L2,
+// and most of the epilogue cost was compiler-inserted vmcnt(0) drains): the main loop is bound by the CU's vector-memory pipe, not by the matrix pipe - 64 LDS-DMA pieces of 1 KiB
 // per K step at ~50 cycles each = the measured 1.6 us per step (17-20 B/clk/CU) - so a group that has the SIMDs to itself
 // still needs 75 % of a full step's bytes for 50 % of its FLOPs, and the stores go through the same pipe.  To build it:
 // add this file to clipa_amd/build.py SOURCES, declare gemm_nts_eligible / gemm_nts_launch in gemm_common.h and route
