@@ -9,6 +9,8 @@
 // RESULT (profiles/r02_gemm_a3b2_ring_ab.jsonl): bit-identical to the production kernel on the first run (six epilogues, four
 // production shapes, two ragged ones) and within +-3 % of its speed everywhere (K = 4096: -1...-5 %, N = K = 1024: +1...+7 %): two
 // steps of landing time for the A operand change nothing, so the A stream's HBM latency is not what the K step waits for either.
+// The mirrored ring (three B slots, two A slots: clipa_gemm_nt7, profiles/r02_gemm_b3a2_ring_ab.jsonl) is bit-identical too and within
+// -4...+3 %: neither operand's landing time alone is the constraint.
 // Self-contained: tools/build_variant.sh nt6 experiments/gemm_nt6_a3b2_ring.hip ; entry point clipa_gemm_nt6 (signature of
 // clipa_gemm_nt, bf16 output, K > 64); tools/gemm_nt4_ab.py nt6 compares it with the production kernel.
 #include "../gemm_common.h"
@@ -21,7 +23,9 @@ constexpr int A_SLOT = IMG_BYTES;                  // 32 KiB: 256 rows x 128 B
 constexpr int B_BASE = 3 * IMG_BYTES;              // B slots behind the three A slots
 constexpr int LDS6_BYTES = 5 * IMG_BYTES;          // 160 KiB
 
-template <int EPI, bool PRE>
+// B3 = false: A has the three slots (clipa_gemm_nt6); B3 = true: B has them (clipa_gemm_nt7) - the weight matrix is most of the
+// fabric traffic (re-streamed from Infinity Cache once per tile group), so its landing time is the other candidate.
+template <int EPI, bool PRE, bool B3>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt6_kernel(NTArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -58,9 +62,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt6_kernel(NTArgs p) {
     m0 = (g * GM + mm) * BM;
     n0 = tn * BN;
   };
+  // the operand with three slots lives at [0, 96 KiB), the other at [96, 160 KiB); `slot` indexes within the operand's region
+  constexpr int A_OFF = B3 ? B_BASE : 0, B_OFF = B3 ? 0 : B_BASE;
   auto stage_a = [&](int slot, int m0, int k0) {
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A + (size_t)m0 * p.lda * 2, (unsigned)(min(BM, p.M - m0) * p.lda * 2));
-    char* sA = smem + slot * A_SLOT;
+    char* sA = smem + A_OFF + slot * A_SLOT;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const unsigned oob = (k0 + kel[j] >= p.K) ? 0x80000000u : 0u;
@@ -69,7 +75,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt6_kernel(NTArgs p) {
   };
   auto stage_b = [&](int slot, int n0, int k0) {
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B + (size_t)n0 * p.ldb * 2, (unsigned)(min(BN, p.N - n0) * p.ldb * 2));
-    char* sB = smem + B_BASE + slot * A_SLOT;
+    char* sB = smem + B_OFF + slot * A_SLOT;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const unsigned oob = (k0 + kel[j] >= p.K) ? 0x80000000u : 0u;
@@ -84,9 +90,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt6_kernel(NTArgs p) {
   // global K-step counter gk: A of step g lives in A slot g % 3 (sa), B in B slot g & 1
   unsigned gk = 0;
   int sa = 0;                                  // gk % 3
-  stage_a(0, m0, 0);
-  stage_b(0, n0, 0);
-  stage_a(1, m0, BK);
+  auto stage_x = [&](int slot, int mt, int nt, int k0) { if (B3) stage_b(slot, nt, k0); else stage_a(slot, mt, k0); };   // three slots
+  auto stage_y = [&](int slot, int mt, int nt, int k0) { if (B3) stage_a(slot, mt, k0); else stage_b(slot, nt, k0); };   // two slots
+  stage_x(0, m0, n0, 0);
+  stage_y(0, m0, n0, 0);
+  stage_x(1, m0, n0, BK);
   RING_WAIT_ALL();
   for (;;) {
     const bool has_next = it + gx < len;
@@ -102,13 +110,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt6_kernel(NTArgs p) {
     for (int kt = 0; kt < nkt; ++kt, ++gk) {
       const int sa1 = sa == 2 ? 0 : sa + 1, sa2 = sa1 == 2 ? 0 : sa1 + 1;
       // B of the next step first (waited for at the end of this step), then A of the step after next (left in flight)
-      if (kt + 1 < nkt) stage_b((gk + 1) & 1, n0, (kt + 1) * BK);
-      else if (has_next) stage_b((gk + 1) & 1, n1, 0);
+      if (kt + 1 < nkt) stage_y((gk + 1) & 1, m0, n0, (kt + 1) * BK);
+      else if (has_next) stage_y((gk + 1) & 1, m1, n1, 0);
       bool a_issued = false;
-      if (kt + 2 < nkt) { stage_a(sa2, m0, (kt + 2) * BK); a_issued = true; }
-      else if (has_next) { stage_a(sa2, m1, (kt + 2 - nkt) * BK); a_issued = true; }
-      const char* sA = smem + sa * A_SLOT;
-      const char* sB = smem + B_BASE + (gk & 1) * A_SLOT;
+      if (kt + 2 < nkt) { stage_x(sa2, m0, n0, (kt + 2) * BK); a_issued = true; }
+      else if (has_next) { stage_x(sa2, m1, n1, (kt + 2 - nkt) * BK); a_issued = true; }
+      const char* sA = smem + A_OFF + (B3 ? (int)(gk & 1) : sa) * A_SLOT;
+      const char* sB = smem + B_OFF + (B3 ? sa : (int)(gk & 1)) * A_SLOT;
       const int l15 = lane & 15, g4 = lane >> 4, sw16 = (l15 >> 1) & 7;
       const char* pa = sA + (wm * 128 + l15) * 128;
       const char* pb = sB + (wn * 64 + l15) * 128;
@@ -146,9 +154,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt6_kernel(NTArgs p) {
     }
 
     // ---- epilogue: window = the B slot of the last K step, vectors parked in its A slot (sa was advanced: last step's = sa - 1) ----
-    char* cb = smem + B_BASE + ((gk + 1) & 1) * A_SLOT;     // gk was advanced: B slot gk & 1 holds the next tile's first step
+    char* cb = smem + B_BASE + ((gk + 1) & 1) * A_SLOT;     // gk was advanced: two-slot region, slot gk & 1 holds the next tile's first step
     const int sa_last = sa == 0 ? 2 : sa - 1;
-    char* park = smem + sa_last * A_SLOT;
+    char* park = smem + sa_last * A_SLOT;                   // three-slot region, the last step's slot
     const bool use_bias = p.bias && !(p.abl & 4);
     if (use_bias) {
       // no LDS is free during the last K step in this layout: the bias vector is fetched here (a short exposed L2 round trip)
@@ -189,15 +197,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt6_kernel(NTArgs p) {
   }
 }
 
-std::once_flag g_nt6_once[MAX_DEVICES];
-int g_nt6_rc[MAX_DEVICES];
+std::once_flag g_nt6_once[2][MAX_DEVICES];
+int g_nt6_rc[2][MAX_DEVICES];
 
 }  // namespace
 }  // namespace clipa_gemm
 
 using namespace clipa_gemm;
 
-extern "C" int clipa_gemm_nt6(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int64_t M, int64_t N,
+template <bool B3>
+static int launch_nt6(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int64_t M, int64_t N,
                               int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldaux, float alpha, int epi, int act, int out_f32,
                               void* stream) {
   if (M <= 0 || N <= 0) return CLIPA_OK;
@@ -208,16 +217,16 @@ extern "C" int clipa_gemm_nt6(const void* A, const void* B, void* C, void* C2, c
   }
   int dev = 0;
   if (int rc = current_device(&dev)) return rc;
-  std::call_once(g_nt6_once[dev], [dev]() {
+  std::call_once(g_nt6_once[B3][dev], [dev]() {
     int rc = 0;
-    const void* v[5] = {(const void*)gemm_nt6_kernel<CLIPA_EPI_NONE, false>, (const void*)gemm_nt6_kernel<CLIPA_EPI_ACT, false>,
-                        (const void*)gemm_nt6_kernel<CLIPA_EPI_ACT, true>, (const void*)gemm_nt6_kernel<CLIPA_EPI_ADD, false>,
-                        (const void*)gemm_nt6_kernel<CLIPA_EPI_DACT, false>};
+    const void* v[5] = {(const void*)gemm_nt6_kernel<CLIPA_EPI_NONE, false, B3>, (const void*)gemm_nt6_kernel<CLIPA_EPI_ACT, false, B3>,
+                        (const void*)gemm_nt6_kernel<CLIPA_EPI_ACT, true, B3>, (const void*)gemm_nt6_kernel<CLIPA_EPI_ADD, false, B3>,
+                        (const void*)gemm_nt6_kernel<CLIPA_EPI_DACT, false, B3>};
     for (int i = 0; i < 5; ++i)
       if (hipFuncSetAttribute(v[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS6_BYTES) != hipSuccess) rc = CLIPA_ERR_LAUNCH;
-    g_nt6_rc[dev] = rc;
+    g_nt6_rc[B3][dev] = rc;
   });
-  if (g_nt6_rc[dev]) return g_nt6_rc[dev];
+  if (g_nt6_rc[B3][dev]) return g_nt6_rc[B3][dev];
   NTArgs a;
   a.A = (const char*)A; a.B = (const char*)B; a.C = (char*)C; a.C2 = (char*)C2; a.bias = bias; a.aux = (const char*)aux;
   a.M = (int)M; a.N = (int)N; a.K = (int)K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
@@ -227,7 +236,7 @@ extern "C" int clipa_gemm_nt6(const void* A, const void* B, void* C, void* C2, c
   const int num_cu = gemm_num_cu(dev);
   const unsigned grid = (unsigned)(tiles < num_cu ? tiles : num_cu);
   hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_NT6(E, P2) hipLaunchKernelGGL((gemm_nt6_kernel<E, P2>), dim3(grid), dim3(NTHREADS), LDS6_BYTES, st, a)
+#define LAUNCH_NT6(E, P2) hipLaunchKernelGGL((gemm_nt6_kernel<E, P2, B3>), dim3(grid), dim3(NTHREADS), LDS6_BYTES, st, a)
   if (epi == CLIPA_EPI_NONE) LAUNCH_NT6(CLIPA_EPI_NONE, false);
   else if (epi == CLIPA_EPI_ACT && C2) LAUNCH_NT6(CLIPA_EPI_ACT, true);
   else if (epi == CLIPA_EPI_ACT) LAUNCH_NT6(CLIPA_EPI_ACT, false);
@@ -236,3 +245,8 @@ extern "C" int clipa_gemm_nt6(const void* A, const void* B, void* C, void* C2, c
 #undef LAUNCH_NT6
   return clipa_check_launch("gemm_nt6<bf16>");
 }
+
+#define NT6_ARGS const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int64_t M, int64_t N, int64_t K, int64_t lda, \
+                 int64_t ldb, int64_t ldc, int64_t ldaux, float alpha, int epi, int act, int out_f32, void* stream
+extern "C" int clipa_gemm_nt6(NT6_ARGS) { return launch_nt6<false>(A, B, C, C2, bias, aux, M, N, K, lda, ldb, ldc, ldaux, alpha, epi, act, out_f32, stream); }
+extern "C" int clipa_gemm_nt7(NT6_ARGS) { return launch_nt6<true>(A, B, C, C2, bias, aux, M, N, K, lda, ldb, ldc, ldaux, alpha, epi, act, out_f32, stream); }
