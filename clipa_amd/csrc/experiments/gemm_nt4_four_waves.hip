@@ -7,8 +7,8 @@
 // tools/gemm_lib_ab-style comparison of whole outputs for all six epilogues on four shapes) and 0.72-0.83x its speed
 // (profiles/r02_gemm_four_wave_variant_ab.jsonl, profiles/r02_gemm_counted_waits.md section 5).
 //
-// What it took to get hipcc to emit it without scratch (scratch loads / stores count on vmcnt and would break the hand-counted
-// waits of window_epilogue):
+// What it took to get hipcc to emit it without scratch (scratch loads / stores sit on vmcnt too: they cannot make a hand-counted
+// wait of window_epilogue too short, only stricter, but they are memory round trips in the hot path):
 //   * accumulators cleared by volatile `v_accvgpr_write_b32 a, 0` - a plain `= 0` is hoisted by the loop rotation above the
 //     previous tile's epilogue, and all 256 live accumulators are then shuffled through the arch VGPRs;
 //   * accumulators read back in the pack callback by volatile `v_accvgpr_read_b32` ("a" operands) - otherwise the scheduler

@@ -144,7 +144,8 @@ struct WinOut {
 constexpr int win_stores(bool pre) { return pre ? 32 : 16; }
 
 // prepare(pass): the packing waves load what pack(ai, bj) needs for this pass (bias / scale vectors parked in LDS: held in
-// registers across the passes they would push the aux epilogues into scratch, whose loads and stores would break the counts).
+// registers across the passes they would push the aux epilogues into scratch: a spill's loads and stores sit on the same counter -
+// extra operations can only make a counted wait stricter, never too short, but each reload is a round trip in the epilogue).
 // ROLL: aux chunks in 16 registers instead of 32 - chunk j's register is refilled for the next pass right after its use
 // (gemm_nt_f8, whose scale arithmetic needs the other 16).
 template <int EPI, bool PRE, bool ROLL, typename Prepare, typename Pack>

@@ -1,7 +1,9 @@
 """The window epilogue of gemm_nt2<bf16> / gemm_nt_f8 (clipa_amd/csrc/gemm_common.h) counts `s_waitcnt vmcnt(N)` by hand around
 inline-asm loads.  This test cross-compiles the two kernels to gfx950 assembly (no GPU needed) and replays the counts with
 tools/audit_hidden_loads.py: no instruction may touch the destination of a hidden load that can still be in flight, and no
-instantiation may use scratch (a spill's loads and stores would shift every count)."""
+instantiation may use scratch (a spill's loads and stores sit on the same counter: they cannot make a counted wait too short -
+extra younger operations only make it stricter - but every reload is a memory round trip inside the epilogue, and the counts
+are only exact, i.e. the stores only stay in flight, when nothing else is issued)."""
 import os
 import re
 import shutil
