@@ -191,6 +191,7 @@ def main():
         if dist_on:
             step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], static_graph=True)
     loss_fn = clipa_amd.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True, rank=rank, world_size=world)
+    loss_fn.bind(model)      # image-feature all-gather starts right after the image tower, on a side stream
 
     B = args.batch
     from clipa_amd.data import synthetic_batch

@@ -101,11 +101,12 @@ def create_model(
     return model
 
 
-def create_loss(args):
-    """factory.py:262-290 (plain ClipLoss branch)."""
+def create_loss(args, model=None):
+    """factory.py:262-290 (plain ClipLoss branch).  `model` (optional, engine extension): bind the loss to the model so
+    that the image-feature all-gather starts under the text tower (ClipLoss.bind)."""
     if getattr(args, "distill", False) or "coca" in getattr(args, "model", "").lower():
         raise NotImplementedError("clipa_amd.create_loss: distillation / CoCa losses are out of scope")
-    return ClipLoss(
+    loss = ClipLoss(
         local_loss=args.local_loss,
         gather_with_grad=args.gather_with_grad,
         cache_labels=True,
@@ -113,6 +114,7 @@ def create_loss(args):
         world_size=args.world_size,
         use_horovod=getattr(args, "horovod", False),
     )
+    return loss.bind(model) if model is not None else loss
 
 
 def create_model_and_transforms(model_name: str, pretrained: Optional[str] = None, precision: str = 'fp32',

@@ -7,10 +7,13 @@ Drop-in for `open_clip.loss.ClipLoss` (clipa_torch/open_clip/loss.py:92-157) and
 
 MI355X mapping.
 * Gather: each rank's embeddings travel as bf16 over RCCL (torch.distributed backend "nccl" is RCCL on ROCm; xGMI
-  underneath) on a side HIP stream.  The IMAGE embeddings are gathered EARLY: `CLIP.forward` hands them to
-  `early_gather()` as soon as the image tower's projection + normalisation are done, so the all-gather runs
-  concurrently with the whole text tower on the compute stream; the loss picks the result up (`_PENDING`) and only
-  the text gather is exposed.  (The reference gathers both serially after both towers, loss.py:73-76.)
+  underneath) on a side HIP stream.  The IMAGE embeddings can be gathered EARLY: after `loss.bind(model)` (explicit
+  opt-in, one line next to create_loss) `CLIP.forward` hands them to `ClipLoss.early_gather()` as soon as the image
+  tower's projection + normalisation are done, so the all-gather runs concurrently with the whole text tower on the
+  compute stream; the loss picks the result up (`self._pending`, matched by tensor IDENTITY) and only the text gather
+  is exposed.  (The reference gathers both serially after both towers, loss.py:73-76.)  All of that state lives on the
+  ClipLoss instance; a forward whose features never reach the loss unchanged (accum_freq > 1 concatenates them,
+  train.py:242-247) costs one unused gather, after which the instance stops gathering early.
 * Backward of the differentiable gather = ONE reduce-scatter(SUM) of the fused [W*B, 2E] fp32 gradient - the
   semantics of torch.distributed.nn.all_gather's backward used by the reference.
 * Similarity GEMM and cross-entropy are ONE kernel pair (`ops.simce`, csrc/simce.hip): the GEMM epilogue reduces each
@@ -20,6 +23,8 @@ MI355X mapping.
   of 8 are zero-padded to the GEMM granularity; the pad columns are excluded from the softmax inside the kernel.
 * Host-side glue that stays in torch: `torch.cat` / `+` of the [B, E] gradient pieces in backward (a few MB).
 """
+import weakref
+
 import torch
 import torch.distributed as dist
 from torch import nn
@@ -28,9 +33,7 @@ from . import ops
 
 bf16, f32 = torch.bfloat16, torch.float32
 
-_SIDE = {}
-_EARLY = {"world_size": 1, "group": None}     # set by ClipLoss.__init__ when world_size > 1
-_PENDING = {}                                 # feature data_ptr -> (local bf16, gathered bf16, side-stream event)
+_SIDE = {}                                    # device -> side stream (created once per device, never mutated afterwards)
 
 
 def _side_stream(device):
@@ -57,24 +60,6 @@ def _all_gather_bf16(local, world_size, group=None):
         return out, ev
     dist.all_gather_into_tensor(out, local, group=group)
     return out, None
-
-
-def early_gather(features):
-    """Called by CLIP.forward right after the image tower: start the all-gather of the (normalised, f32 [B, E]) image
-    features on the side stream so that it overlaps the text tower.  No-op unless a multi-rank ClipLoss exists."""
-    W = _EARLY["world_size"]
-    if W <= 1 or not dist.is_available() or not dist.is_initialized():
-        return
-    local = ops.to_bf16(features.detach())
-    gathered, ev = _all_gather_bf16(local, W, _EARLY["group"])
-    _PENDING.clear()                                  # at most one step in flight
-    _PENDING[features.data_ptr()] = (local, gathered, ev)
-
-
-def _take_pending(features):
-    ent = _PENDING.pop(features.data_ptr(), None)
-    _PENDING.clear()
-    return ent
 
 
 def _reduce_scatter_fused(full, world_size, group=None):
@@ -105,10 +90,9 @@ class ClipLossFn(torch.autograd.Function):
     """(CE(logits_per_image, y) + CE(logits_per_text, y)) / 2 with logits = s * I . T^T."""
 
     @staticmethod
-    def forward(ctx, img, txt, logit_scale, local_loss, gather_with_grad, rank, world_size, group):
+    def forward(ctx, img, txt, logit_scale, local_loss, gather_with_grad, rank, world_size, group, pend=None):
         B, E = img.shape
         s_dev = logit_scale.detach().to(f32).reshape(1).contiguous()     # stays on the device
-        pend = _take_pending(img) if world_size > 1 else None
         tb = ops.to_bf16(txt)
         if world_size > 1:
             t_all, t_ev = _all_gather_bf16(tb, world_size, group)
@@ -174,7 +158,8 @@ class ClipLossFn(torch.autograd.Function):
         d_s = ops.sum_scale(dsi, 1.0)
         ops.sum_scale(dst, 1.0, out=d_s, accumulate=True)
         g = dloss.to(f32)
-        return ((d_i * g).to(idt), (d_t * g).to(tdt), (d_s * g).to(sdt).reshape(sshape), None, None, None, None, None)
+        return ((d_i * g).to(idt), (d_t * g).to(tdt), (d_s * g).to(sdt).reshape(sshape), None, None, None, None, None,
+                None)
 
 
 class ClipLoss(nn.Module):
@@ -192,12 +177,43 @@ class ClipLoss(nn.Module):
         self.world_size = world_size
         self.use_horovod = use_horovod
         self.group = group
-        # a multi-rank loss object exists: let CLIP.forward start the image-feature gather before the text tower
-        _EARLY["world_size"], _EARLY["group"] = world_size, group
+        self._pending = None        # (weakref(features), version, local bf16, gathered bf16, side-stream event)
+        self._early_ok = True       # cleared when an early gather went unused (features re-packed before the loss)
+
+    def bind(self, model):
+        """Opt in to the overlapped image-feature gather: `model` (a clipa_amd.CLIP, possibly inside DDP) will call
+        `self.early_gather` from its forward.  EVERY rank must then run the same grad-enabled training forwards (the
+        call is a collective), exactly as every rank must call the loss.  Returns self."""
+        getattr(model, "module", model)._gather_partner = weakref.ref(self)
+        return self
+
+    def early_gather(self, features):
+        """Start the all-gather of the (normalised, f32 [B, E]) image features on the side stream so that it overlaps
+        the text tower.  No-op for a single rank or once an early gather has gone unused."""
+        if self.world_size <= 1 or not self._early_ok or not dist.is_available() or not dist.is_initialized():
+            return
+        if self._pending is not None:          # the previous forward never reached the loss with its own tensor
+            self._pending, self._early_ok = None, False
+            return
+        local = ops.to_bf16(features.detach())
+        gathered, ev = _all_gather_bf16(local, self.world_size, self.group)
+        self._pending = (weakref.ref(features), features._version, local, gathered, ev)
+
+    def _take_pending(self, features):
+        ent, self._pending = self._pending, None
+        if ent is None:
+            return None
+        if ent[0]() is features and ent[1] == features._version:
+            return ent[2:]
+        self._early_ok = False                 # e.g. accum_freq > 1: the loss sees torch.cat(...) of cached features
+        return None
 
     def forward(self, image_features, text_features, logit_scale, output_dict=False):
-        if not torch.is_tensor(logit_scale):
-            logit_scale = torch.tensor(float(logit_scale), device=image_features.device)
-        total_loss = ClipLossFn.apply(image_features.float(), text_features.float(), logit_scale, self.local_loss,
-                                      self.gather_with_grad, self.rank, self.world_size, self.group)
+        pend = self._take_pending(image_features) if self.world_size > 1 else None
+        # the reference trainer calls the loss inside torch.autocast (train.py:203-213); the kernels take fixed dtypes
+        with torch.autocast(device_type=image_features.device.type, enabled=False):
+            if not torch.is_tensor(logit_scale):
+                logit_scale = torch.tensor(float(logit_scale), device=image_features.device)
+            total_loss = ClipLossFn.apply(image_features.float(), text_features.float(), logit_scale, self.local_loss,
+                                          self.gather_with_grad, self.rank, self.world_size, self.group, pend)
         return {"contrastive_loss": total_loss} if output_dict else total_loss

@@ -284,6 +284,7 @@ class CLIP(nn.Module):
         if text_cfg.hf_model_name or text_cfg.embed_cls:
             _unsupported("HF text towers / embed_cls")
         self._cache = engine.WeightCache()
+        self._gather_partner = None          # weakref to a ClipLoss that opted in with loss.bind(model)
         self.visual = VisionTransformer(
             image_size=vision_cfg.image_size, patch_size=vision_cfg.patch_size, width=vision_cfg.width,
             layers=vision_cfg.layers, heads=vision_cfg.width // vision_cfg.head_width, mlp_ratio=vision_cfg.mlp_ratio,
@@ -363,18 +364,21 @@ class CLIP(nn.Module):
         return engine.L2NormFn.apply(features) if normalize else features
 
     def forward(self, image, text):
-        image_features = self.encode_image(image, normalize=True)
-        if self.training and torch.is_grad_enabled():
-            # MI355X engine: if a multi-rank ClipLoss exists, the RCCL all-gather of the image embeddings starts now,
-            # on a side stream, and runs under the text tower (clipa_amd.loss.early_gather; north_star: "overlapped
-            # ... on a side HIP stream").  Single-rank / eval: no-op.
-            from . import loss as _loss
-            _loss.early_gather(image_features)
-        text_features = self.encode_text(text, normalize=True)
+        # the reference trainer runs the model under torch.autocast(bfloat16) (train.py:160,203-205; precision.py:6-14):
+        # every FLOP here is a HIP kernel with its own fixed operand types, so autocast is switched off for the glue
+        with torch.autocast(device_type=image.device.type, enabled=False):
+            image_features = self.encode_image(image, normalize=True)
+            partner = self._gather_partner() if self._gather_partner is not None else None
+            if partner is not None and self.training and torch.is_grad_enabled():
+                # MI355X engine: a multi-rank ClipLoss bound to this model (`loss.bind(model)`) starts the RCCL
+                # all-gather of the image embeddings now, on a side stream, under the text tower (north_star:
+                # "overlapped ... on a side HIP stream").  Single rank / eval / not bound: nothing happens.
+                partner.early_gather(image_features)
+            text_features = self.encode_text(text, normalize=True)
+            logit_scale = self.logit_scale.exp()
         if self.output_dict:
-            return {"image_features": image_features, "text_features": text_features,
-                    "logit_scale": self.logit_scale.exp()}
-        return image_features, text_features, self.logit_scale.exp()
+            return {"image_features": image_features, "text_features": text_features, "logit_scale": logit_scale}
+        return image_features, text_features, logit_scale
 
 
 def convert_weights_to_lp(model: nn.Module, dtype=torch.bfloat16):

@@ -4,6 +4,8 @@ current-stream plumbing.  No arithmetic happens here - every op below is one or 
 import ctypes
 import math
 
+import threading
+
 import torch
 
 from . import lib
@@ -370,6 +372,7 @@ def assemble_tokens_bwd(dtok, B, L, need_pos=True):
 # The count is fetched without stalling the stream (pinned buffer + event) and checked at the next embedding call or by
 # `check_token_ids()`: a bad id surfaces as a RuntimeError at most one step late.
 _OOB_PENDING = []
+_OOB_LOCK = threading.Lock()      # appended to from the autograd thread (embed_tokens_bwd), drained from the main thread
 
 
 def _oob_counter(device):
@@ -381,22 +384,29 @@ def _oob_submit(counter, what, msg="token ids outside [0, vocab) (nn.Embedding w
     host.copy_(counter, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
-    _OOB_PENDING.append((host, ev, (what, msg), counter))
+    with _OOB_LOCK:
+        _OOB_PENDING.append((host, ev, (what, msg), counter))
 
 
 def check_token_ids(wait=False):
     """Raise if an earlier embedding forward / backward met token ids outside the table (wait=True: block on all)."""
-    keep = []
-    for host, ev, what, counter in _OOB_PENDING:
+    with _OOB_LOCK:
+        pending = list(_OOB_PENDING)
+        _OOB_PENDING.clear()
+    keep, bad = [], None
+    for host, ev, what, counter in pending:
         if wait:
             ev.synchronize()
         if ev.query():
-            if int(host[0]) != 0:
-                _OOB_PENDING.clear()
-                raise RuntimeError(f"clipa_amd.ops.{what[0]}: {int(host[0])} {what[1]}")
+            if int(host[0]) != 0 and bad is None:
+                bad = f"clipa_amd.ops.{what[0]}: {int(host[0])} {what[1]}"
         else:
             keep.append((host, ev, what, counter))
-    _OOB_PENDING[:] = keep
+    if bad is not None:
+        raise RuntimeError(bad)      # everything submitted so far is dropped with it
+    if keep:
+        with _OOB_LOCK:
+            _OOB_PENDING[:0] = keep
 
 
 def embed_tokens(ids, table, pos):

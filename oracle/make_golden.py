@@ -61,6 +61,8 @@ FULL_CASES = {
     "full_H14_224": dict(json="ViT-H-14.json", B=2, S=224, seed=23),                 # BASELINE config 4 (head dim 80)
     "full_L16_84_gap": dict(json="ViT-L-16-CL32-GAP.json", B=4, S=84, seed=24, ctx=77,   # BASELINE config 5a: 26 tokens,
                             vision_extra={"pos_embed": "sin_cos_2d"}),                   # GAP, frozen sin-cos table
+    # BASELINE config 1 at its stated dimensions: ViT-S/16 @ 112 px (50 tokens), text ctx 32, local batch 64
+    "full_S16_112_t32": dict(json="ViT-S-16.json", B=64, S=112, seed=25, ctx=32),
 }
 
 

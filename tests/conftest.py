@@ -12,8 +12,9 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 MODEL_CASES = ["cls_erf", "gap_sincos_tanh", "bigvision_quick", "h14_dh80"]
 # full model dimensions at BASELINE shapes (ViT-L/16, ViT-B/16, ViT-H/14 @ 224 + text-77; ViT-L/16 @ 84 GAP / sin-cos),
-# generated from the reference's own model_configs/*.json by oracle/make_golden.py
-FULL_CASES = ["full_B16_224", "full_L16_224", "full_H14_224", "full_L16_84_gap"]
+# and BASELINE config 1 at its stated dimensions: ViT-S/16 @ 112, text-32, batch 64), generated from the reference's own
+# model_configs/*.json by oracle/make_golden.py
+FULL_CASES = ["full_B16_224", "full_L16_224", "full_H14_224", "full_L16_84_gap", "full_S16_112_t32"]
 
 
 def pytest_configure(config):

@@ -43,7 +43,7 @@ def _worker(rank, world, port, q):
     ddp = torch.nn.parallel.DistributedDataParallel(m, static_graph=True)
     B = g.images_u8.shape[0] // world
     img, txt = g.images_u8[rank * B:(rank + 1) * B], g.texts[rank * B:(rank + 1) * B]
-    loss_fn = clipa_amd.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True, rank=rank, world_size=world)
+    loss_fn = clipa_amd.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True, rank=rank, world_size=world).bind(ddp)
     losses = []
     for _ in range(2):
         ddp.zero_grad(set_to_none=True)

@@ -81,7 +81,7 @@ def _worker(rank, world, port, q, accum=1):
     import clipa_amd
     model = _build(dev)
     ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], static_graph=True)
-    loss_fn = clipa_amd.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True, rank=rank, world_size=world)
+    loss_fn = clipa_amd.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True, rank=rank, world_size=world).bind(ddp)
     img, txt = _batch(world)
     img = img[rank * B_LOC:(rank + 1) * B_LOC].to(dev)
     txt = txt[rank * B_LOC:(rank + 1) * B_LOC].to(dev)
@@ -200,7 +200,7 @@ def _sharded_worker(rank, world, port, q):
     model = _build(dev)
     opt = ShardedAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3, betas=(0.9, 0.95), eps=1e-6, weight_decay=0.1,
                        grad_clip_norm=1.0, bucket_bytes=8 << 20)
-    loss_fn = clipa_amd.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True, rank=rank, world_size=world)
+    loss_fn = clipa_amd.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True, rank=rank, world_size=world).bind(model)
     img, txt = _batch(world)
     img = img[rank * B_LOC:(rank + 1) * B_LOC].to(dev)
     txt = txt[rank * B_LOC:(rank + 1) * B_LOC].to(dev)

@@ -172,7 +172,7 @@ def _clip_worker(rank, world, port, q):
                        clamp=(m.logit_scale, 0.0, math.log(100)), **dict(HP, lr=2e-3))
     B = g.images_u8.shape[0] // world
     img, txt = g.images_u8[rank * B:(rank + 1) * B], g.texts[rank * B:(rank + 1) * B]
-    loss_fn = clipa_amd.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True, rank=rank, world_size=world)
+    loss_fn = clipa_amd.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True, rank=rank, world_size=world).bind(m)
     losses = []
     for _ in range(3):
         opt.zero_grad()

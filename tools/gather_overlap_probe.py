@@ -21,8 +21,8 @@ from clipa_amd.data import synthetic_batch
 
 model = clipa_amd.create_model("ViT-L-16", precision="bf16", device=dev, force_image_size=224, output_dict=True)
 model.set_grad_checkpointing(True)
-loss_fn = clipa_amd.ClipLoss(local_loss=True, gather_with_grad=True, rank=0, world_size=1)
-L._EARLY["world_size"] = 2          # pretend a second rank exists so that CLIP.forward issues the early gather ...
+loss_fn = clipa_amd.ClipLoss(local_loss=True, gather_with_grad=True, rank=0, world_size=1).bind(model)
+loss_fn.world_size = 2              # pretend a second rank exists so that CLIP.forward issues the early gather ...
 images, texts = synthetic_batch(args.batch, 224, 77, 49408, seed=1, device=dev)
 
 marks = {}
@@ -64,7 +64,8 @@ for it in range(3):
     t0.record()
     model.train()
     feats_i = model.encode_image(images, normalize=True)
-    L.early_gather(feats_i)
+    loss_fn.early_gather(feats_i)
+    loss_fn._pending = None
     feats_t = model.encode_text(texts, normalize=True)
     torch.cuda.synchronize()
     g0, g1 = marks["gather"][0]
@@ -77,5 +78,4 @@ for it in range(3):
            "text_tower_end_ms": round(x0.elapsed_time(x1), 3),
            "gather_inside_text_tower": bool(t0.elapsed_time(g1) <= t0.elapsed_time(x1))}
     print(json.dumps(rec), flush=True)
-L._PENDING.clear()
 dist.destroy_process_group()
