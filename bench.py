@@ -33,6 +33,17 @@ ROOFLINE_KERNELS = {
 }
 
 
+def kernel_source_sha16():
+    """Identity of the GEMM kernel sources a PMC measurement belongs to (profiles/traffic.json)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "clipa_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.startswith("gemm_") and os.path.isfile(os.path.join(d, f)):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def train_gflop_per_pair(cfg, S, ctx):
     """SURVEY.md 8d: F_tower = layers*L*(24 D^2 + 4 L D), patch GEMM, projections; training = 3x forward;
     activation recompute NOT counted."""
@@ -107,6 +118,8 @@ def cpu_baseline(cfg, S, ctx, sample_pairs, threads):
         n += 1
     dt = (time.perf_counter() - t0) / n
     return {"value": sample_pairs / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+            # measured in the build container (tools/cpu_port_vs_reference.py, 8 threads, same weights / batch / loss to 1e-7)
+            "port_over_reference": {"time_ratio": [1.03, 1.14], "source": "profiles/r02_cpu_port_vs_reference.txt"},
             "sample": f"{sample_pairs} pairs/step x {n} timed steps (+1 warm-up), fp32 fwd+loss+bwd+AdamW, "
                       f"oracle/clip_oracle.py on torch CPU ops"}
 
@@ -137,9 +150,12 @@ def main():
                          "clipa_amd.zero.ShardedAdamW (gradient reduce-scatter, optimizer state / W, parameter all-gather; no DDP wrapper)")
     ap.add_argument("--exchange", default="reduce_scatter", choices=["reduce_scatter", "all_to_all"],
                     help="--optimizer sharded: RCCL reduce-scatter, or one-hop all-to-all over the xGMI mesh + local sum")
-    ap.add_argument("--h2d-steps", type=int, default=2,
+    ap.add_argument("--h2d-steps", type=int, default=5,
                     help="extra steps (after the timed region, not part of `value`) whose batches come from pinned host memory "
                          "through the device input pipeline: reported as `h2d_inclusive` (0 = skip)")
+    ap.add_argument("--plain-steps", type=int, default=3,
+                    help="extra steps after the timed region WITHOUT the per-launch HIP-event instrumentation of clipa_amd.ops: "
+                         "reported as `uninstrumented_ms_per_step` next to `ms_per_step` (0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=8, help="pairs per CPU-baseline step")
     ap.add_argument("--cpu-timeout", type=int, default=240)
     args = ap.parse_args()
@@ -219,12 +235,18 @@ def main():
                     o = step_model(im, tx)
                     for k in feats:
                         feats[k].append(o[k])
+            import contextlib
             for j, (im, tx) in enumerate(chunks):
-                o = step_model(im, tx)
-                scale = o.pop("logit_scale")
-                inputs = {k: torch.cat(v[:j] + [o[k]] + v[j + 1:]) for k, v in feats.items()}
-                loss = loss_fn(**inputs, logit_scale=scale, output_dict=True)["contrastive_loss"]
-                loss.backward()
+                # gradients are exchanged once, by the last micro-batch's backward (DDP.no_sync / ShardedAdamW.no_sync); the
+                # reference's loop all-reduces on every backward, which is correct with both but moves A x the bytes
+                defer = contextlib.nullcontext() if (j == A - 1 or not dist_on) else \
+                    (opt.no_sync() if args.optimizer == "sharded" else step_model.no_sync())
+                with defer:
+                    o = step_model(im, tx)
+                    scale = o.pop("logit_scale")
+                    inputs = {k: torch.cat(v[:j] + [o[k]] + v[j + 1:]) for k, v in feats.items()}
+                    loss = loss_fn(**inputs, logit_scale=scale, output_dict=True)["contrastive_loss"]
+                    loss.backward()
         opt.step()                                             # AdamW + logit_scale clamp, multi-tensor kernels
         return loss
 
@@ -303,6 +325,21 @@ def main():
     if not math.isfinite(last_loss):
         print(f"bench.py: non-finite loss {last_loss}", file=sys.stderr)
         sys.exit(3)
+    # the same step without the ~1100 HIP events per step that feed `roofline` / `kernels` (clipa_amd.ops.profile_start):
+    # quantifies what the instrumentation costs the timed region.  Never part of `value`.
+    plain_ms = None
+    if args.plain_steps > 0:
+        fence()
+        tp = time.perf_counter()
+        for _ in range(args.plain_steps):
+            step()
+        fence()
+        ep = time.perf_counter() - tp
+        if dist_on:
+            tm = torch.tensor([ep], device=dev, dtype=torch.float64)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            ep = float(tm)
+        plain_ms = round(1e3 * ep / args.plain_steps, 2)
 
     # PCIe-inclusive rate (the reference's batch_time includes the H2D copy, train.py:187-189): the same step
     # fed from pinned host memory with staged uint8 NHWC images through DevicePrefetcher (copy stream, double buffered) +
@@ -353,17 +390,26 @@ def main():
         peak, dom_desc = ROOFLINE_KERNELS[dom]
         nt = prof.get(dom, {"launches": 0, "ms": 0.0, "work": 0.0, "bytes": 0.0})
         achieved = nt["work"] / (nt["ms"] * 1e-3) / 1e12 if nt["ms"] > 0 else 0.0
-        traffic = None
+        # PMC traffic (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes) cannot be collected inside this process: it is read
+        # from profiles/traffic.json, which names the kernel sources it was measured on - and is reported only while they are
+        # unchanged (otherwise null + the reason)
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and dom == "gemm_nt":
             try:
-                traffic = json.load(open(tpath)).get("gemm_nt_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                if tj.get("kernel_source_sha16") == kernel_source_sha16():
+                    traffic = tj.get("gemm_nt_hbm_bytes_per_launch")
+                    traffic_source = f"profiles/traffic.json ({tj.get('measured', 'PMC passes')}; kernel sources {tj.get('kernel_source_sha16')})"
+                else:
+                    traffic_source = (f"stale: profiles/traffic.json was measured on kernel sources {tj.get('kernel_source_sha16')}, "
+                                      f"this build is {kernel_source_sha16()}")
             except Exception:
                 traffic = None
         line = {
             "metric": "image-text pairs/sec (whole job), full training step",
             "value": round(pairs_s, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms, 2), "uninstrumented_ms_per_step": plain_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp8" if args.precision == "fp8" else "bf16", "data": "synthetic",
             "config": {"workload": f"{args.model}@{args.image_size} + text-{args.ctx}, local batch {B}, "
                                    f"global batch {B * world}, " + (f"accum_freq {A} (feature cache: +1 forward per pair), " if A > 1 else "") +
@@ -376,7 +422,7 @@ def main():
             "alloc_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)),
             "roofline": {"bound": "mfma", "kernel": dom_desc, "achieved": round(achieved, 1),
                          "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                         "traffic": traffic, "algorithmic_bytes_per_launch": round(nt.get("bytes", 0.0) / max(nt["launches"], 1)),
+                         "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": round(nt.get("bytes", 0.0) / max(nt["launches"], 1)),
                          "launches": nt["launches"],
                          "avg_launch_ms": round(nt["ms"] / max(nt["launches"], 1), 4)},
             "h2d_inclusive": h2d,

@@ -159,7 +159,8 @@ __global__ void embed_tokens_kernel(const long* __restrict__ ids, const void* __
 // last bits on different runs).  bf16 inputs convert exactly (anything below 2^-45 rounds to 0), the sum is exact, and
 // one rounding to f32 happens in the convert kernel.  Range: |element| <= 2^17, |sum| < 2^19 - far above any gradient
 // of a training run that has not diverged; rows that receive a non-finite element are flagged and come out as NaN (what
-// the float sum would give), an out-of-range element is treated the same way.
+// the float sum would give); a finite element beyond 2^17 SATURATES at +-2^17 instead of poisoning its row.  The token-id
+// range check comes first, so an out-of-range id is counted even when its gradient row is all zero.
 constexpr double EMB_FIX = 17592186044416.0;         // 2^44
 __global__ void embed_tokens_bwd_kernel(const long* __restrict__ ids, const unsigned short* __restrict__ dx,
                                         unsigned long long* __restrict__ acc, unsigned char* __restrict__ bad_row, long B, int T,
@@ -169,20 +170,21 @@ __global__ void embed_tokens_bwd_kernel(const long* __restrict__ ids, const unsi
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int c = (int)(idx % dc);
     const long row = idx / dc;
-    const u32x4 raw = *(const u32x4*)(dx + (size_t)row * D + c * 8);
-    if (((raw[0] | raw[1] | raw[2] | raw[3]) & 0x7fff7fffu) == 0) continue;
     const long id = ids[row];
-    if (id < 0 || id >= vocab) {          // never scatter outside the table: count and skip
+    if (id < 0 || id >= vocab) {          // never scatter outside the table: count (once per row) and skip
       if (c == 0 && oob) atomicAdd(oob, 1);
       continue;
     }
+    const u32x4 raw = *(const u32x4*)(dx + (size_t)row * D + c * 8);
+    if (((raw[0] | raw[1] | raw[2] | raw[3]) & 0x7fff7fffu) == 0) continue;
     float v[8];
     unpack8(raw, v);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       if (v[i] == 0.f) continue;
-      if (!(fabsf(v[i]) <= 131072.0f)) { bad_row[id] = 1; continue; }      // NaN / Inf / out of range: poison the row
-      atomicAdd(acc + (size_t)id * D + c * 8 + i, (unsigned long long)__double2ll_rn((double)v[i] * EMB_FIX));
+      if (!(fabsf(v[i]) <= 3.0e38f)) { bad_row[id] = 1; continue; }        // NaN / Inf: the row comes out as NaN
+      const float vs = fminf(fmaxf(v[i], -131072.0f), 131072.0f);          // finite but beyond the fixed-point range: saturate
+      atomicAdd(acc + (size_t)id * D + c * 8 + i, (unsigned long long)__double2ll_rn((double)vs * EMB_FIX));
     }
   }
 }

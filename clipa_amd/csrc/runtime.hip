@@ -90,9 +90,11 @@ __global__ void adamw_multi_kernel(MTArgs a) {
   }
 }
 
-// sum of squares of many gradient tensors (clip_grad_norm_'s total norm, train.py:270-277): block partial -> one atomic
+// sum of squares of many gradient tensors (clip_grad_norm_'s total norm, train.py:270-277): one partial per block, summed
+// in a FIXED order by sqnorm_reduce_kernel - no float atomics, so the clip coefficient (and with it every parameter update)
+// is bit-reproducible run to run, like the other reductions of the step
 template <bool GF32>
-__global__ void sqnorm_multi_kernel(MTArgs a, float* __restrict__ acc) {
+__global__ void sqnorm_multi_kernel(MTArgs a, float* __restrict__ partials) {
   __shared__ float red[4];
   int t = 0;
   while (t + 1 < a.count && (int)blockIdx.x >= a.blk0[t + 1]) ++t;
@@ -107,7 +109,20 @@ __global__ void sqnorm_multi_kernel(MTArgs a, float* __restrict__ acc) {
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// acc[0] += sum of partials[0..n): thread t adds partials t, t+256, ... in order, then a fixed tree over the 256 threads
+__global__ void sqnorm_reduce_kernel(const float* __restrict__ partials, long n, float* __restrict__ acc) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (long i = threadIdx.x; i < n; i += 256) s += partials[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) acc[0] += red[0];
 }
 __global__ void clip_coef_kernel(const float* __restrict__ acc, float max_norm, float* __restrict__ norm_out, float* __restrict__ coef_out) {
   const float n = sqrtf(acc[0]);
@@ -118,10 +133,14 @@ __global__ void clip_coef_kernel(const float* __restrict__ acc, float max_norm, 
 }  // namespace
 
 extern "C" int clipa_grad_sqnorm_multi(const void* const* grads, const int64_t* numel, int count, int grad_f32, float* acc,
-                                       void* stream) {
+                                       float* partials, int64_t partials_cap, void* stream) {
   if (count <= 0) return CLIPA_OK;
-  if (!grads || !numel || !acc) { clipa_set_error("grad_sqnorm_multi: null argument"); return CLIPA_ERR_ARG; }
+  if (!grads || !numel || !acc || !partials) { clipa_set_error("grad_sqnorm_multi: null argument"); return CLIPA_ERR_ARG; }
+  long need = 0;
+  for (int i = 0; i < count; ++i) need += numel[i] > 0 ? (numel[i] + MT_CHUNK - 1) / MT_CHUNK : 0;
+  if (need > partials_cap) { clipa_set_error("grad_sqnorm_multi: partials holds %ld floats, %ld needed (one per %d elements of every tensor)", (long)partials_cap, need, MT_CHUNK); return CLIPA_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
+  long done = 0;
   for (int next = 0; next < count;) {
     MTArgs a;
     a.count = 0;
@@ -136,9 +155,14 @@ extern "C" int clipa_grad_sqnorm_multi(const void* const* grads, const int64_t* 
     next = i;
     if (a.count == 0) continue;
     const unsigned grid = (unsigned)a.blk0[a.count];
-    if (grad_f32) hipLaunchKernelGGL(sqnorm_multi_kernel<true>, dim3(grid), dim3(256), 0, st, a, acc);
-    else hipLaunchKernelGGL(sqnorm_multi_kernel<false>, dim3(grid), dim3(256), 0, st, a, acc);
+    if (grad_f32) hipLaunchKernelGGL(sqnorm_multi_kernel<true>, dim3(grid), dim3(256), 0, st, a, partials + done);
+    else hipLaunchKernelGGL(sqnorm_multi_kernel<false>, dim3(grid), dim3(256), 0, st, a, partials + done);
     if (int rc = clipa_check_launch("grad_sqnorm_multi")) return rc;
+    done += grid;
+  }
+  if (done > 0) {
+    hipLaunchKernelGGL(sqnorm_reduce_kernel, dim3(1), dim3(256), 0, st, partials, done, acc);
+    if (int rc = clipa_check_launch("grad_sqnorm_reduce")) return rc;
   }
   return CLIPA_OK;
 }

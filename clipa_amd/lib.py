@@ -57,7 +57,7 @@ SIGNATURES = {
     "clipa_sum_scale": (_I32, [_P, _P, _I64, _F, _I32, _P]),
     "clipa_adamw": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _F, _F, _F, _F, _F, _I64, _F, _P]),
     "clipa_adamw_multi": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _F, _F, _F, _F, _F, _I64, _F, _P, _I32, _F, _F, _P]),
-    "clipa_grad_sqnorm_multi": (_I32, [_P, _P, _I32, _I32, _P, _P]),
+    "clipa_grad_sqnorm_multi": (_I32, [_P, _P, _I32, _I32, _P, _P, _I64, _P]),
     "clipa_clip_coef": (_I32, [_P, _F, _P, _P, _P]),
     "clipa_reduce_shards": (_I32, [_P, _P, _I64, _I32, _I32, _I32, _F, _P]),
 }

@@ -620,7 +620,9 @@ def grad_sqnorm(grads, buf=None):
         n = len(sel)
         arr = ctypes.c_void_p * n
         cnt = (ctypes.c_int64 * n)(*[g.numel() for g in sel])
-        lib.call("clipa_grad_sqnorm_multi", arr(*[g.data_ptr() for g in sel]), cnt, n, int(is32), _p(buf), _stream())
+        nblk = sum((g.numel() + 4095) // 4096 for g in sel)            # one partial per 4096-element block, summed in a fixed order
+        part = torch.empty(max(nblk, 1), device=dev, dtype=f32)
+        lib.call("clipa_grad_sqnorm_multi", arr(*[g.data_ptr() for g in sel]), cnt, n, int(is32), _p(buf), _p(part), nblk, _stream())
     return buf
 
 

@@ -31,7 +31,7 @@ from . import ops
 
 class _Bucket:
     __slots__ = ("group", "params", "offsets", "numel", "flat", "grad", "shard", "gshard", "recv", "m", "v", "arrived",
-                 "handle", "launched")
+                 "handle", "launched", "stale")
 
 
 class ShardedAdamW(torch.optim.Optimizer):
@@ -107,25 +107,35 @@ class ShardedAdamW(torch.optim.Optimizer):
         b.recv = None
         b.m = torch.zeros(n, dtype=torch.float32, device=device)
         b.v = torch.zeros(n, dtype=torch.float32, device=device)
-        b.arrived, b.handle, b.launched = 0, None, False
+        b.arrived, b.handle, b.launched, b.stale = 0, None, False, False
         for p in plist:
             p.register_post_accumulate_grad_hook(lambda _p, b=b: self._on_grad(b))
         self.buckets.append(b)
 
     # ---- gradient exchange ----------------------------------------------------------------------------------------------
     def _on_grad(self, b):
-        if not self._sync:
-            return
+        """A gradient of bucket `b` has been accumulated.  The reference's accum_freq loop (train.py:243-256) calls backward()
+        several times per optimizer step with no no_sync(): a backward that lands after the bucket's exchange was launched
+        makes that exchange stale, and every completed round of arrivals (re-)exchanges the CUMULATIVE flat gradient - what
+        DDP does when it all-reduces on every backward.  Inside no_sync() nothing is exchanged; step() catches up."""
         b.arrived += 1
-        if b.arrived == len(b.params) and not b.launched:
+        if b.launched:
+            b.stale = True
+        if self._sync and b.arrived % len(b.params) == 0:
             self._launch(b)
 
     def _launch(self, b):
-        b.launched = True
+        if b.handle is not None:                                  # superseded exchange of an earlier backward: let it drain
+            b.handle.wait()
+            b.handle = None
+        b.launched, b.stale = True, False
         if not self._collect:
             return
         if not self._tensor_collectives:
-            b.handle = dist.all_reduce(b.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            # gloo (tests): all-reduce a COPY - in place it would fold other ranks' sums into the local accumulator that a
+            # later backward of the same step keeps adding to
+            b.recv = b.grad.clone()
+            b.handle = dist.all_reduce(b.recv, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         elif self.exchange == "all_to_all":
             if b.recv is None:
                 b.recv = torch.empty_like(b.grad)
@@ -136,14 +146,15 @@ class ShardedAdamW(torch.optim.Optimizer):
             b.handle = dist.reduce_scatter_tensor(b.gshard, b.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _finish(self, b):
-        if not b.launched:                                        # parameters that received no gradient this step, or no_sync
-            self._launch(b)
+        if not b.launched or b.stale:                             # no gradient hook completed a round (unused parameters,
+            self._launch(b)                                       # no_sync), or gradients arrived after the last exchange
         if b.handle is not None:
             b.handle.wait()
             b.handle = None
             n = b.numel // self.world
             if not self._tensor_collectives:
-                b.gshard.copy_(b.grad[self.rank * n:(self.rank + 1) * n])
+                b.gshard.copy_(b.recv[self.rank * n:(self.rank + 1) * n])
+                b.recv = None
             elif self.exchange == "all_to_all":
                 ops.reduce_shards(b.recv, self.world, out=b.gshard, scale=1.0)
 
@@ -159,8 +170,11 @@ class ShardedAdamW(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):
         """Gradients are views of the flat buffers: one memset per bucket, never None."""
         for b in self.buckets:
+            if b.handle is not None:                              # an exchange nobody consumed (zero_grad without step)
+                b.handle.wait()
+                b.handle = None
             b.grad.zero_()
-            b.arrived, b.launched = 0, False
+            b.arrived, b.launched, b.stale = 0, False, False
             for p, o in zip(b.params, b.offsets):
                 if p.grad is None or p.grad.data_ptr() != b.grad.data_ptr() + o * b.grad.element_size():
                     p.grad = b.grad[o:o + p.numel()].view(p.shape)
@@ -213,7 +227,7 @@ class ShardedAdamW(torch.optim.Optimizer):
             self.clamp[0].data.clamp_(self.clamp[1], self.clamp[2])
         self._bump_versions()
         for b in self.buckets:
-            b.arrived, b.launched = 0, False
+            b.arrived, b.launched, b.stale = 0, False, False
         return loss
 
     # ---- checkpoint interchange (training/main.py:338-356, 436-468): the layout of torch.optim.AdamW.state_dict() ----------
@@ -229,7 +243,10 @@ class ShardedAdamW(torch.optim.Optimizer):
         return full
 
     def state_dict(self):
-        """COLLECTIVE (every rank must call it): full, un-sharded state in torch.optim.AdamW's format."""
+        """COLLECTIVE: every rank must call it (the moments are sharded; this all-gathers them) - full, un-sharded state in
+        torch.optim.AdamW's format.  The reference builds its checkpoint dict only on the master rank (main.py:437-443,
+        inside `if args.save_logs`): with this optimizer hoist `opt_state = optimizer.state_dict()` above that branch
+        (INTEGRATION.md section 1), or rank 0 blocks in the gather while the other ranks train on."""
         index = {}
         k = 0
         for g in self.param_groups:

@@ -193,9 +193,11 @@ int clipa_adamw_multi(void* const* params, const void* const* grads, float* cons
                       void* stream);
 /* torch.nn.utils.clip_grad_norm_ (train.py:270-277) without a host round trip: acc[0] += sum of squares of the listed
  * gradients (zero it first; call once per dtype bucket), then coef = min(1, max_norm / (sqrt(acc) + 1e-6)) and the
- * norm itself land in device memory for clipa_adamw_multi's grad_scale_dev. */
+ * norm itself land in device memory for clipa_adamw_multi's grad_scale_dev.  `partials` is caller-provided scratch of at
+ * least sum_i ceil(numel[i] / 4096) floats: block partials are summed in a fixed order (no float atomics - the coefficient is
+ * bit-reproducible run to run). */
 int clipa_grad_sqnorm_multi(const void* const* grads, const int64_t* numel, int count, int grad_f32, float* acc,
-                            void* stream);
+                            float* partials, int64_t partials_cap, void* stream);
 int clipa_clip_coef(const float* acc, float max_norm, float* norm_out, float* coef_out, void* stream);
 /* Sharded gradient exchange (replaces the ring all-reduce of the DDP wrapper, training/main.py:292-299):
  * out[i] = scale * sum over w < W of in[w*n + i] - the local sum of the W shard pieces a rank receives in the one-hop

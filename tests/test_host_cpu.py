@@ -227,3 +227,20 @@ def test_keep_plan_is_rank_invariant():
         assert p.exitcode == 0
     assert got[0][1] == got[1][1] == 150 << 30
     assert got[0][2] == got[1][2]
+
+
+@pytest.mark.skipif(not ref_loader.available(), reason="/root/reference not mounted")
+@pytest.mark.parametrize("unlocked", [0, 1, 2, 3])
+def test_lock_image_tower_freezes_the_reference_set(unlocked):
+    """model.py:229-231 / transformer.py:415-446: the set of parameters left trainable by lock_image_tower(unlocked_groups=k)
+    is the reference's (groups: [stem], block 0 .. block n-2, [last block, ln_post], proj)."""
+    ref_model, _, _ = ref_loader.load()
+    g = load_golden("cls_erf")
+    ref = ref_model.CLIP(**g.cfg)
+    ref.lock_image_tower(unlocked_groups=unlocked)
+    mine = clipa_amd.CLIP(**g.cfg)
+    mine.lock_image_tower(unlocked_groups=unlocked)
+    want = {k: p.requires_grad for k, p in ref.named_parameters()}
+    got = {k: p.requires_grad for k, p in mine.named_parameters()}
+    assert got == want
+    assert not any(v for k, v in got.items() if k.startswith("visual.conv1"))

@@ -135,6 +135,43 @@ def test_gemm_nt_production_rows():
     assert torch.isfinite(out.float()).all()
 
 
+@pytest.mark.parametrize("N,K", [(4096, 1024), (1024, 4096)])
+def test_gemm_nt_production_width_values(N, K):
+    """VALUE-level check of the real launch shapes of the MLP GEMMs (M = 806 912 = ViT-L/16 @ 224 x local batch 4096;
+    c_fc: N = 4096, K = 1024; c_proj: N = 1024, K = 4096) against fp64 on sampled rows, for every fused epilogue: bias,
+    GELU (+ pre-activation copy), residual add, GELU-backward.  ~3 150 x 16 (x 4) persistent tiles of 256 x 256."""
+    o = ops()
+    M = 806912
+    g = torch.Generator(device=DEV).manual_seed(100 + N)
+    a = torch.randn(M, K, generator=g, device=DEV, dtype=f32).to(bf16)
+    b = (torch.randn(N, K, generator=g, device=DEV, dtype=f32) * (1.0 / math.sqrt(K))).to(bf16)
+    bias = torch.randn(N, generator=g, device=DEV, dtype=f32)
+    aux = torch.randn(M, N, generator=g, device=DEV, dtype=bf16)
+    gc = torch.Generator().manual_seed(7)
+    rows = torch.cat([torch.arange(0, 260), torch.arange(M - 260, M), torch.randint(0, M, (1500,), generator=gc),
+                      torch.tensor([2 ** 18 - 1, 2 ** 18, 2 ** 19, 2 ** 19 + 255, 524288 + 131072, 255, 256, 511, 512])]).to(DEV)
+    lin = a[rows].double().cpu() @ b.double().cpu().T + bias.double().cpu()
+    v = lin.to(bf16).double()                                  # the engine rounds the GEMM result to bf16 before the epilogue
+    auxr = aux[rows].double().cpu()
+    out = o.gemm_nt(a, b, bias)
+    check("bias", out[rows], lin, 2 ** -7, 2e-3)
+    assert torch.isfinite(out.float()).all()
+    del out
+    act, pre = o.gemm_nt(a, b, bias, epi=o.EPI_ACT, act=0, want_pre=True)
+    check("pre-activation", pre[rows], lin, 2 ** -7, 2e-3)
+    check("gelu", act[rows], ref_act(pre[rows].double().cpu(), 0), 2 ** -7, 2e-3)
+    act1 = o.gemm_nt(a, b, bias, epi=o.EPI_ACT, act=0)
+    assert torch.equal(act1, act), "one-output and two-output activation epilogues differ"
+    del act, act1, pre
+    out = o.gemm_nt(a, b, bias, epi=o.EPI_ADD, aux=aux)
+    check("residual add", out[rows], v + auxr, 2 ** -7, 1.6e-2)
+    del out
+    x = auxr.clone().requires_grad_(True)
+    ref_act(x, 0).sum().backward()
+    out = o.gemm_nt(a, b, bias, epi=o.EPI_DACT, act=0, aux=aux)
+    check("gelu backward", out[rows], v * x.grad, 2 ** -6, 6e-3)
+
+
 def test_gemm_tn_production_rows():
     """Reduction over M = 806 912 rows (the weight-gradient launch shape), R = C = 256, against fp64."""
     o = ops()

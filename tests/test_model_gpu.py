@@ -272,3 +272,41 @@ def test_zero_shot_classifier_and_logits_match_oracle():
     tgt = ref_logits.argmax(1)
     top1, top5 = Z.run(m, clf, n, [(g.images_u8.to(DEV), tgt.to(DEV))])
     assert top5 == 1.0 and top1 >= 0.75
+
+
+@pytest.mark.parametrize("unlocked", [0, 1, 2])
+def test_lock_image_tower_on_gpu(unlocked):
+    """open_clip/model.py:229-231, transformer.py:415-446 on the HIP engine: frozen image-tower parameters get no gradient,
+    the trainable ones (text tower, logit_scale, the unlocked groups) get exactly the gradient of the unfrozen model, and the
+    backward of a frozen prefix is skipped without touching the rest."""
+    g = load_golden("cls_erf")
+    full = _engine(g)
+    _step(full, g)
+    ref = {k: p.grad.clone() for k, p in full.named_parameters() if p.grad is not None}
+    m = _engine(g)
+    m.lock_image_tower(unlocked_groups=unlocked)
+    _, loss = _step(m, g)
+    n_frozen = 0
+    for k, p in m.named_parameters():
+        if not p.requires_grad:
+            assert k.startswith("visual.") and p.grad is None, k
+            n_frozen += 1
+        else:
+            assert p.grad is not None, k
+            assert torch.equal(p.grad, ref[k]), k
+    assert n_frozen > 0
+    if unlocked == 0:
+        assert all(not p.requires_grad for p in m.visual.parameters())
+    else:
+        assert m.visual.proj.requires_grad
+    # the oracle agrees on the trainable gradients (frozen leaves simply have no .grad there either)
+    sd = {k: v.clone().requires_grad_(dict(m.named_parameters())[k].requires_grad if k in dict(m.named_parameters()) else False)
+          for k, v in g.sd.items()}
+    i, t, s = O.clip_forward(sd, g.ocfg, O.normalize_images(g.images_u8), g.texts)
+    lo, _ = O.clip_loss(i, t, s)
+    lo.backward()
+    assert abs(float(loss) - float(lo)) < 2e-2 * float(lo)
+    for k, p in m.named_parameters():
+        if p.requires_grad and p.grad.numel() > 1 and float(sd[k].grad.norm()) > 1e-7:
+            a, b = p.grad.double().cpu().reshape(-1), sd[k].grad.double().reshape(-1)
+            assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.99, k

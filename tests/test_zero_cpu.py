@@ -89,7 +89,7 @@ def test_single_process_equals_fused_adamw(cpu_ops_swapped):
         assert torch.equal(p, q)
 
 
-def _toy_worker(rank, world, port, q, exchange):
+def _toy_worker(rank, world, port, q, exchange, mode="no_sync"):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -101,10 +101,19 @@ def _toy_worker(rank, world, port, q, exchange):
     xs = [torch.randn(16, 24) for _ in range(3)]
     for step in range(2):
         opt.zero_grad()
-        with opt.no_sync():                                            # two micro-batches accumulate, the third exchanges
+        if mode == "no_sync":
+            with opt.no_sync():                                        # two micro-batches accumulate, the third exchanges
+                (m(xs[0]) ** 2).mean().backward()
+                (m(xs[1]) ** 2).mean().backward()
+            (m(xs[2]) ** 2).mean().backward()
+        elif mode == "plain":                                          # the reference's accum loop (train.py:243-256): backward()
+            for x in xs:                                               # accum_freq times, NO no_sync - every bucket re-exchanges
+                (m(x) ** 2).mean().backward()
+        else:                                                          # sync backward first, no_sync afterwards: step() must catch up
             (m(xs[0]) ** 2).mean().backward()
-            (m(xs[1]) ** 2).mean().backward()
-        (m(xs[2]) ** 2).mean().backward()
+            with opt.no_sync():
+                (m(xs[1]) ** 2).mean().backward()
+                (m(xs[2]) ** 2).mean().backward()
         opt.step()
     sd = opt.state_dict()
     q.put((rank, [p.detach().numpy().copy() for p in m.parameters()], float(opt.last_grad_norm),
@@ -129,9 +138,13 @@ def _spawn(target, world, port, *args):
     return got
 
 
-def test_two_rank_sharded_step_equals_adamw_on_averaged_gradient():
+@pytest.mark.parametrize("mode,port", [("no_sync", 29771), ("plain", 29775), ("sync_then_no_sync", 29777)])
+def test_two_rank_sharded_step_equals_adamw_on_averaged_gradient(mode, port):
+    """Three ways of accumulating three micro-batches before one step - inside no_sync (one exchange), plain repeated
+    backward() as the reference's accum_freq loop does (every completed round re-exchanges the cumulative gradient), and
+    an exchange that later backwards make stale - all equal AdamW on the rank-averaged accumulated gradient."""
     world = 2
-    got = _spawn(_toy_worker, world, 29771, "reduce_scatter")
+    got = _spawn(_toy_worker, world, port, "reduce_scatter", mode)
     _swap()
     try:
         from clipa_amd.optim import AdamW
