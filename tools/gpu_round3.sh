@@ -1,0 +1,40 @@
+#!/bin/bash
+# Round-3 GPU sessions.  Usage: gpurun --timeout N -- 'bash tools/gpu_round3.sh [stage...]'
+set -u
+mkdir -p gpurun_out
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+R="$PWD"
+STAGES="${*:-alltests bench}"
+for s in $STAGES; do
+  case $s in
+    alltests)
+      timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -s > gpurun_out/pytest_gpu.log 2>&1
+      echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log ;;
+    newtests)
+      timeout 900 python -m pytest tests/test_trainer_gpu.py tests/test_model_gpu.py tests/test_kernels_gpu.py -m gpu -q --tb=short -p no:cacheprovider -s \
+        -k "trainer or autocast or fused_adamw or lock_image or production or S16 or gemm_nt" > gpurun_out/pytest_new.log 2>&1
+      echo "pytest rc=$?" >> gpurun_out/pytest_new.log ;;
+    bench)
+      timeout 900 python bench.py --shapes > gpurun_out/bench.log 2>&1; echo "rc=$?" >> gpurun_out/bench.log ;;
+    benchq)
+      timeout 600 python bench.py --shapes --steps 3 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 > gpurun_out/benchq.log 2>&1; echo "rc=$?" >> gpurun_out/benchq.log ;;
+    gemmab)
+      timeout 600 ./tools/probes/gemm_nt_asm_ab "${GEMMAB_ARGS:-}" > gpurun_out/gemm_nt_asm_ab.log 2>&1; echo "rc=$?" >> gpurun_out/gemm_nt_asm_ab.log ;;
+    smoke)
+      timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "rc=$?" >> gpurun_out/smoke.log ;;
+    stats)
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof" -o r03 -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 > "$R/gpurun_out/bench_prof.log" 2>&1)
+      db=$(find gpurun_out/prof -name '*.db' | head -1)
+      [ -n "$db" ] && python tools/rocpd_stats.py "$db" > gpurun_out/kernel_stats.csv 2>&1 ;;
+    pmcbench)
+      mkdir -p gpurun_out/pmcbench
+      for set in FETCH_SIZE WRITE_SIZE; do
+        (cd /tmp && timeout 400 rocprofv3 --pmc $set -d "$R/gpurun_out/pmcbench/$set" -o pmc -- \
+           python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 --keep-blocks 0,0,24,4 > "$R/gpurun_out/pmcbench/$set.log" 2>&1)
+      done
+      python tools/pmc_summary.py gpurun_out/pmcbench gemm attn > gpurun_out/pmcbench_summary.txt 2>&1 ;;
+    *) echo "unknown stage $s" ;;
+  esac
+done
+ls -la gpurun_out | tail -30
