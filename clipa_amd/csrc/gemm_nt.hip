@@ -357,6 +357,12 @@ extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, co
   a.alpha = alpha; a.epi = epi; a.act = act; a.abl = g_abl.load(std::memory_order_relaxed);
   a.gm = nt_group_size((N + BN - 1) / BN, 256L * K * 2);
   hipStream_t st = (hipStream_t)stream;
+  // whole-tile bf16 shapes (every block GEMM of the BASELINE configurations at batch multiples of 256) run on the four-wave
+  // kernel with the hand-scheduled main loop (gemm_nta.hip); bit-identical outputs.  clipa_debug_set(1, .) keeps them on
+  // gemm_nt2, clipa_debug_set(2 + s, .) selects generated schedule s (A/B harnesses)
+  const int variant = g_nt_variant.load(std::memory_order_relaxed);
+  if (variant != 1 && !(a.abl & 15) && nta_eligible(a, out_f32))
+    return nta_launch(a, dev, num_cu, variant >= 2 ? variant - 2 : 0, st);
   const long tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   if (out_f32) {
     const unsigned grid = (unsigned)(tiles < num_cu ? tiles : num_cu);
