@@ -14,6 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libclipa_hip.so")
 SOURCES = ["gemm_nt.hip", "gemm_nta.hip", "gemm_tn.hip", "gemm_f8.hip", "quant.hip", "simce.hip", "layernorm.hip", "attention.hip", "misc.hip", "augment.hip", "runtime.hip"]
+AUDITED = {"gemm_nta.hip": "audit_nta.py"}          # source -> tools/<script> run on its device assembly
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", CSRC, "-I", os.path.join(ROOT, "include"),
          "-Wno-unused-result", "-ffp-contract=fast"]
@@ -43,6 +44,8 @@ def build(force=False, verbose=False):
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if src in AUDITED:
+            cmd.append("-save-temps=obj")            # keeps the device assembly next to the object for the audit below
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -50,6 +53,13 @@ def build(force=False, verbose=False):
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
         if verbose and r.stderr.strip():
             print(r.stderr)
+        if src in AUDITED:
+            # hand-counted waits / literally named registers are only valid for the code hipcc actually emitted: the static
+            # audits are part of the build, not only of the test-suite
+            asm = os.path.join(objdir, src.replace(".hip", "-hip-amdgcn-amd-amdhsa-gfx950.s"))
+            a = subprocess.run([sys.executable, os.path.join(ROOT, "tools", AUDITED[src]), asm], capture_output=True, text=True)
+            if a.returncode != 0:
+                raise RuntimeError(f"ISA audit of {src} failed ({AUDITED[src]}):\n{a.stdout[-3000:]}\n{a.stderr[-2000:]}")
         return obj
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:

@@ -1,0 +1,63 @@
+"""gemm_nta (clipa_amd/csrc/gemm_nta.hip): the main loop is generated text and the accumulators live in registers hipcc does
+not know about.  Without a GPU this checks that (1) the committed gemm_nta_asm.inc IS what tools/gen_gemm_nta.py generates,
+(2) every schedule keeps the pipeline's ordering rules (slot freed before it is re-filled, publish wait after the step's last
+LDS-DMA, fragment registers not re-loaded before their last use), and (3) the cross-compiled ISA passes tools/audit_nta.py:
+no scratch, no compiler-generated access to an accumulation register, 512 registers per wave."""
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_inc_is_up_to_date():
+    import gen_gemm_nta as G
+    assert open(G.OUT).read() == G.render(), "run: python tools/gen_gemm_nta.py"
+
+
+@pytest.mark.parametrize("sched", [0, 1, 2])
+def test_schedule_ordering_rules(sched):
+    import gen_gemm_nta as G
+    S = G.SCHEDULES[sched]
+    lines = G.step_text(S, 0, "cur", False, False, "16", False)
+    pos = {k: [] for k in ("mfma", "rd", "dma", "m0", "bar", "vm", "lgk")}
+    for i, l in enumerate(lines):
+        key = ("mfma" if l.startswith("v_mfma") else "rd" if l.startswith("ds_read") else "dma" if l.startswith("buffer_load") else
+               "m0" if l.startswith("s_add_u32 m0") else "bar" if l == "s_barrier" else "vm" if l.startswith("s_waitcnt vmcnt") else
+               "lgk" if l.startswith("s_waitcnt lgkmcnt") else None)
+        if key:
+            pos[key].append(i)
+    assert len(pos["mfma"]) == 128 and len(pos["rd"]) == 32 and len(pos["dma"]) == 16 and len(pos["bar"]) == 2
+    rd1, rd0 = pos["rd"][:16], pos["rd"][16:]
+    assert max(rd1) < pos["lgk"][0] < pos["bar"][0] < min(pos["dma"])          # slot freed (all waves) before the DMA re-fills it
+    assert max(pos["dma"]) < pos["vm"][0] < pos["bar"][1] < min(rd0)           # publish: own DMA counted, then barrier, then reads
+    assert max(rd0) < pos["lgk"][1]
+    for d, m in zip(pos["dma"], pos["m0"]):                                    # an M0 write needs a wait state before its LDS-DMA
+        assert m < d and any(m < x < d for x in pos["mfma"])
+    # write-after-read on the fragment registers: k-half-0 registers are re-loaded only after the 64 MFMAs that read them
+    assert min(rd0) > pos["mfma"][63]
+    # k-half-1 registers of block b are re-loaded (at the top of the NEXT step) after their last reader of this step
+    regs = lambda l: re.findall(r"v\[(\d+):", l)
+    for i in rd1:
+        dst = regs(lines[i])[0]
+        readers = [j for j in pos["mfma"] if dst in regs(lines[j])[0:2] or f"v[{dst}:" in lines[j]]
+        assert all(j > i for j in readers if j >= pos["mfma"][64])             # within a step the read precedes its k-half-1 users
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason="hipcc not available")
+def test_isa_audit(tmp_path):
+    asm = tmp_path / "gemm_nta.s"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "clipa_amd", "csrc"), "-I",
+           os.path.join(ROOT, "include"), "-Wno-unused-result", "-ffp-contract=fast", "-S", "--cuda-device-only", "-o", str(asm),
+           os.path.join(ROOT, "clipa_amd", "csrc", "gemm_nta.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_nta.py"), str(asm)], capture_output=True, text=True)
+    assert a.returncode == 0, a.stdout[-3000:]
+    assert len(re.findall(r"\.name:\s+\S*gemm_nta_kernel", asm.read_text())) == 15
