@@ -301,6 +301,7 @@ extern std::atomic<int> g_abl;            // clipa_debug_set: experiment flags
 constexpr int MAX_DEVICES = 64;
 
 // gemm_nta.hip: the four-wave / hand-scheduled kernel for whole-tile bf16 shapes (clipa_gemm_nt dispatches to it)
+constexpr int NTA_DEFAULT_SCHEDULE = 4;   // profiles/r03_gemm_nta_schedules_0_7_mainloop_ablation.jsonl
 bool nta_eligible(const NTArgs& a, int out_f32);
 int nta_launch(const NTArgs& a, int dev, int num_cu, int sched, hipStream_t st);
 

@@ -361,8 +361,8 @@ extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, co
   // kernel with the hand-scheduled main loop (gemm_nta.hip); bit-identical outputs.  clipa_debug_set(1, .) keeps them on
   // gemm_nt2, clipa_debug_set(2 + s, .) selects generated schedule s (A/B harnesses)
   const int variant = g_nt_variant.load(std::memory_order_relaxed);
-  if (variant != 1 && !(a.abl & 15) && nta_eligible(a, out_f32))
-    return nta_launch(a, dev, num_cu, variant >= 2 ? variant - 2 : 0, st);
+  if (variant != 1 && !(a.abl & 13) && nta_eligible(a, out_f32))
+    return nta_launch(a, dev, num_cu, variant >= 2 ? variant - 2 : NTA_DEFAULT_SCHEDULE, st);
   const long tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   if (out_f32) {
     const unsigned grid = (unsigned)(tiles < num_cu ? tiles : num_cu);

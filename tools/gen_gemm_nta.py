@@ -41,7 +41,22 @@ SCHEDULES = {
     1: dict(rd1_start=0, rd1_stride=1, bar1=20, dma_start=22, dma_stride=2, vmwait=88, rd0_start=90, rd0_stride=2, lgk_end=126),
     # DMA spread one per three MFMAs, publish as late as the fragment reads allow
     2: dict(rd1_start=0, rd1_stride=2, bar1=34, dma_start=36, dma_stride=3, vmwait=92, rd0_start=94, rd0_stride=2, lgk_end=126),
+    # DMA one per four MFMAs (the issue spans half a K step), read-ahead packed into the last 24 MFMAs
+    3: dict(rd1_start=0, rd1_stride=2, bar1=34, dma_start=36, dma_stride=4, vmwait=100, rd0_start=102, rd0_stride=1, lgk_end=126),
+    # early slot release (reads one per MFMA) + DMA one per four MFMAs
+    4: dict(rd1_start=0, rd1_stride=1, bar1=20, dma_start=22, dma_stride=4, vmwait=96, rd0_start=98, rd0_stride=1, lgk_end=126),
+    # schedule 2 with the publish point pushed to MFMA 104
+    5: dict(rd1_start=0, rd1_stride=2, bar1=34, dma_start=36, dma_stride=3, vmwait=104, rd0_start=106, rd0_stride=1, lgk_end=126),
+    # early release, DMA one per six MFMAs: the issue spans the step, the publish wait leaves the DMA issued before it in flight
+    6: dict(rd1_start=0, rd1_stride=1, bar1=20, dma_start=22, dma_stride=6, vmwait=96, rd0_start=98, rd0_stride=1, lgk_end=126),
+    # early release, DMA one per five MFMAs, publish after the last one
+    7: dict(rd1_start=0, rd1_stride=1, bar1=20, dma_start=22, dma_stride=5, vmwait=100, rd0_start=102, rd0_stride=1, lgk_end=126),
 }
+
+
+def younger(S):
+    """LDS-DMA of a step issued before its publish wait (the wait sits after MFMA `vmwait`, DMA q after MFMA dma_start + 1 + q stride)."""
+    return sum(1 for q in range(16) if S["dma_start"] + 1 + q * S["dma_stride"] <= S["vmwait"])
 
 
 def acc(bj, ai):
@@ -69,6 +84,7 @@ def step_text(S, slot, srd, first, last, vmcnt, bias):
     fill[S["bar1"]] += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
     # LDS-DMA of step + 2 into the slot just freed
     m = S["dma_start"]
+    assert m > S["bar1"]
     if bias:
         for p in range(4):
             for h in range(2):
@@ -81,9 +97,11 @@ def step_text(S, slot, srd, first, last, vmcnt, bias):
         fill[m + 1].append(f"buffer_load_dwordx4 v{voff}, %[{srd}{s}], %[sk] offen lds")
         m += S["dma_stride"]
     last_dma = m - S["dma_stride"] + 1
+    assert last_dma + 1 < 127
     fill[last_dma + 1].append("s_add_u32 %[sk], %[sk], 128")
     if not last:
-        assert last_dma < S["vmwait"]
+        # step + 1's operands are older than everything this step has issued so far: `younger(S)` LDS-DMA may stay in flight
+        assert vmcnt in ("@VM0@", str(younger(S)))
         fill[S["vmwait"]] += [f"s_waitcnt vmcnt({vmcnt})", "s_barrier"]
         m = S["rd0_start"]
         for kind, b in order:
@@ -138,19 +156,20 @@ def tile_text(S):
     t = setup_text()
     t.append("s_mov_b32 %[sk], 256")
     # this tile's step 0 has landed (younger: step 1's 16 LDS-DMA + whatever the epilogue before us left in flight)
-    t += ["s_waitcnt vmcnt(@VM0@)", "s_barrier"]
+    t += ["s_waitcnt vmcnt(@VMS@)", "s_barrier"]
     for kind, b in order:
         base, addr = (B0, VADDR_B) if kind == "B" else (A0, VADDR_A)
         t.append(f"ds_read_b128 {vr(base, b)}, v{addr} offset:{b * BLOCK}")
     t.append("s_waitcnt lgkmcnt(0)")
     t += step_text(S, 0, "cur", True, False, "@VM0@", False)
-    t += step_text(S, 1, "cur", False, False, "16", False)
+    k = str(younger(S))
+    t += step_text(S, 1, "cur", False, False, k, False)
     t += ["s_cmp_eq_u32 %[nloop], 0", "s_cbranch_scc1 NTA_TAIL_%=", "s_mov_b32 %[cnt], %[nloop]", "NTA_LOOP_%=:"]
-    t += step_text(S, 0, "cur", False, False, "16", False)
-    t += step_text(S, 1, "cur", False, False, "16", False)
+    t += step_text(S, 0, "cur", False, False, k, False)
+    t += step_text(S, 1, "cur", False, False, k, False)
     t += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 NTA_LOOP_%=", "NTA_TAIL_%=:",
           "s_mov_b32 %[sk], 0"]
-    t += step_text(S, 0, "nxt", False, False, "16", False)
+    t += step_text(S, 0, "nxt", False, False, k, False)
     t += step_text(S, 1, "nxt", False, True, None, True)
     # the bias is older than the 16 LDS-DMA of the last step; MFMA results must be readable by v_accvgpr_read afterwards
     t += ["s_waitcnt vmcnt(16)", "s_nop 7", "s_nop 7"]
@@ -160,9 +179,10 @@ def tile_text(S):
 def c_string(lines, indent="  "):
     out = []
     for l in lines:
-        if "@VM0@" in l:                       # the one immediate that differs per instantiation: macro argument, stringified
-            a, b = l.split("@VM0@")
-            out.append(f'{indent}"{a}" #VM0 "{b}\\n\\t"')
+        if "@VM0@" in l or "@VMS@" in l:       # the immediates that differ per instantiation: macro arguments, stringified
+            name = "VM0" if "@VM0@" in l else "VMS"
+            a, b = l.split(f"@{name}@")
+            out.append(f'{indent}"{a}" #{name} "{b}\\n\\t"')
         else:
             out.append(f'{indent}"{l}\\n\\t"')
     return "\n".join(out)
@@ -189,10 +209,20 @@ def render():
     p.append(" \\\n".join(c_string(prologue_text()).split("\n")))
     p.append("")
     for v, S in SCHEDULES.items():
+        k = younger(S)
         p.append(f"// schedule {v}: {S}")
-        p.append(f"#define NTA_TILE_ASM_{v}(VM0) \\")
+        p.append(f"// VMS: wait in front of the tile's first fragment reads (16 + stores the epilogue before it may leave in flight);")
+        p.append(f"// VM0: publish wait of the tile's first step ({k} + those stores).  Both capped at the counter's 63.")
+        p.append(f"#define NTA_TILE_ASM_{v}(S) NTA_TILE_ASM_{v}_I(NTA_VMS_##S, NTA_VM0_{v}_##S)")
+        for st in (0, 32, 64):
+            p.append(f"#define NTA_VM0_{v}_{st} {min(63, k + st)}")
+        p.append(f"#define NTA_TILE_ASM_{v}_I(VMS, VM0) NTA_TILE_ASM_{v}_II(VMS, VM0)")
+        p.append(f"#define NTA_TILE_ASM_{v}_II(VMS, VM0) \\")
         p.append(" \\\n".join(c_string(tile_text(S)).split("\n")))
         p.append("")
+    for st in (0, 32, 64):
+        p.append(f"#define NTA_VMS_{st} {min(63, 16 + st)}")
+    p.append("")
     p.append("#define NTA_CLOBBERS \\")
     p.append(" \\\n".join(clobbers().split("\n")))
     p.append("")

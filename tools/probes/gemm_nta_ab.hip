@@ -43,7 +43,7 @@ int main(int argc, char** argv) {
   struct Shape { long M, N, K; };
   std::vector<Shape> shapes = {{200704, 4096, 1024}, {200704, 1024, 4096}, {200704, 3072, 1024}, {200704, 1024, 1024}, {78848, 768, 3072}, {4096, 512, 256}, {512, 256, 384}};
   if (quick) shapes = {{200704, 4096, 1024}, {200704, 1024, 4096}, {512, 256, 384}};
-  const int NV = 4;   // variant 1 = gemm_nt2, 2..4 = gemm_nta schedule 0..2
+  const int NV = 9;   // variant 1 = gemm_nt2, 2..9 = gemm_nta schedule 0..7
   hipStream_t st;
   CK(hipStreamCreate(&st));
   unsigned long long* d_cnt;
@@ -109,6 +109,27 @@ int main(int argc, char** argv) {
       }
       printf("}\n");
       fflush(stdout);
+      if (e.epi == CLIPA_EPI_NONE) {     // main loop only (ablation flag 2): what the epilogues cost on top
+        printf("{\"check\": \"mainloop\", \"M\": %ld, \"N\": %ld, \"K\": %ld", M, N, K);
+        for (int v = 1; v <= NV; ++v) {
+          std::vector<float> t;
+          for (int r = 0; r < 3; ++r) {
+            clipa_debug_set(v, 2);
+            clipa_gemm_nt(A, B, C[1], nullptr, bias, nullptr, M, N, K, K, K, N, N, 1.0f, 0, 0, 0, st);
+            CK(hipEventRecord(e0, st));
+            for (int k = 0; k < reps; ++k) clipa_gemm_nt(A, B, C[1], nullptr, bias, nullptr, M, N, K, K, K, N, N, 1.0f, 0, 0, 0, st);
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float x;
+            CK(hipEventElapsedTime(&x, e0, e1));
+            t.push_back(x / reps);
+          }
+          std::sort(t.begin(), t.end());
+          printf(", \"v%d_tflops\": %.1f", v, 2.0 * M * N * K / (t[1] * 1e-3) / 1e12);
+        }
+        printf("}\n");
+        fflush(stdout);
+      }
     }
     CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(AUX)); CK(hipFree(bias));
     for (int i = 0; i < 2; ++i) { CK(hipFree(C[i])); CK(hipFree(C2[i])); }
