@@ -304,5 +304,8 @@ constexpr int MAX_DEVICES = 64;
 constexpr int NTA_DEFAULT_SCHEDULE = 4;   // profiles/r03_gemm_nta_schedules_0_7_mainloop_ablation.jsonl
 bool nta_eligible(const NTArgs& a, int out_f32);
 int nta_launch(const NTArgs& a, int dev, int num_cu, int sched, hipStream_t st);
+// gemm_tna.hip: the same structure for the weight-gradient product (clipa_gemm_tn dispatches to it)
+bool tna_eligible(const TNArgs& a);
+int tna_launch(const TNArgs& a, int dev, dim3 grid, int sched, hipStream_t st);
 
 }  // namespace clipa_gemm

@@ -457,27 +457,49 @@ extern "C" int clipa_gemm_tn(const void* P, const void* Q, void* out, float* col
   if (int rc = current_device(&dev)) return rc;
   const int abl = g_abl.load(std::memory_order_relaxed);
   const bool per_xcd = tn_per_xcd(M, R, C);
-  const int64_t S = tn_slices(M, R, C, gemm_num_cu(dev), per_xcd);
-  const int64_t need = (S * R * C + S * R) * (int64_t)sizeof(float);
+  const int64_t S_plan = tn_slices(M, R, C, gemm_num_cu(dev), per_xcd);
+  const int64_t need = (S_plan * R * C + S_plan * R) * (int64_t)sizeof(float);
   if (workspace_bytes < need || !workspace) { clipa_set_error("gemm_tn: workspace %ld < %ld bytes", (long)workspace_bytes, (long)need); return CLIPA_ERR_ARG; }
   const long mt = (M + 63) / 64;
-  const long slice_rows = ((mt + S - 1) / S) * 64;
+  const long slice_rows = ((mt + S_plan - 1) / S_plan) * 64;
   if (slice_rows * ldp * 2 >= (1L << 32) - (1 << 24) || slice_rows * ldq * 2 >= (1L << 32) - (1 << 24)) { clipa_set_error("gemm_tn: slice too large for 32-bit buffer offsets"); return CLIPA_ERR_ARG; }
   if (int rc = ensure_tn_attrs(dev)) return rc;
   TNArgs a;
   a.P = (const char*)P; a.Q = (const char*)Q; a.O = (float*)workspace;
   a.M = (int)M; a.R = (int)R; a.C = (int)C; a.ldp = ldp; a.ldq = ldq; a.ldo = C; a.slice_rows = (int)slice_rows;
-  a.colsum = colsum_out ? (float*)workspace + S * R * C : nullptr;
-  a.nslices = per_xcd ? (int)S : 0;
+  a.colsum = colsum_out ? (float*)workspace + S_plan * R * C : nullptr;
+  a.nslices = per_xcd ? (int)S_plan : 0;
   const long tiles = ((R + 255) / 256) * ((C + 255) / 256);
   // The 16x16x32 kernel (v3) for the image tower's wide-P products (in-proj and c_fc weight gradients) and its
   // 1024 x 1024 out-proj, the ping-pong kernel (v2) elsewhere (c_proj, the text tower) - per-shape winners of
   // tools/tn_ab.py, all within +-4 % except the text tower (v2 +18 %).  Experiment flags 1024 / 2048 force v3 / v2.
   const bool use_v3 = (abl & 1024) || (!(abl & 2048) && ((R >= 3072 && C >= 1024) || (R == 1024 && C == 1024)));
-  const dim3 grid = per_xcd ? dim3((unsigned)(tiles * S), 1) : dim3((unsigned)tiles, (unsigned)S);
-  if (use_v3) hipLaunchKernelGGL(gemm_tn3_kernel, grid, dim3(NTHREADS), 2 * STAGE_BYTES, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(gemm_tn2_kernel, grid, dim3(NTHREADS), 2 * STAGE_BYTES, (hipStream_t)stream, a);
-  if (int rc = clipa_check_launch("gemm_tn")) return rc;
+  // Whole-tile shapes with slices of an even number of K steps (every block GEMM of the BASELINE configurations) run on the
+  // four-wave kernel with the hand-scheduled main loop (gemm_tna.hip): slices are rounded up to 128 rows, which may leave
+  // fewer (never more) slices than the workspace was sized for.  Experiment flags: 16384 keeps gemm_tn2/3, 32768 = schedule 1.
+  int64_t S_used = S_plan;
+  bool launched = false;
+  if (!(abl & (16384 | 1024 | 2048))) {
+    TNArgs b = a;
+    b.slice_rows = (int)((slice_rows + 127) / 128 * 128);
+    const int64_t S4 = (M + b.slice_rows - 1) / b.slice_rows;
+    if (per_xcd) b.nslices = (int)S4;
+    if (S4 <= S_plan && tna_eligible(b)) {
+      const dim3 g4 = per_xcd ? dim3((unsigned)(tiles * ((S4 + 7) / 8 * 8)), 1) : dim3((unsigned)tiles, (unsigned)S4);
+      b.colsum = colsum_out ? (float*)workspace + S4 * R * C : nullptr;
+      if (int rc = tna_launch(b, dev, g4, (abl & 32768) ? 1 : 0, (hipStream_t)stream)) return rc;
+      a = b;
+      S_used = S4;
+      launched = true;
+    }
+  }
+  if (!launched) {
+    const dim3 grid = per_xcd ? dim3((unsigned)(tiles * S_plan), 1) : dim3((unsigned)tiles, (unsigned)S_plan);
+    if (use_v3) hipLaunchKernelGGL(gemm_tn3_kernel, grid, dim3(NTHREADS), 2 * STAGE_BYTES, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(gemm_tn2_kernel, grid, dim3(NTHREADS), 2 * STAGE_BYTES, (hipStream_t)stream, a);
+    if (int rc = clipa_check_launch("gemm_tn")) return rc;
+  }
+  const int64_t S = S_used;      // slabs actually written
   const long n = R * C;
   const unsigned blocks = (unsigned)((n / 4 + 255) / 256);
   if (out_bf16) hipLaunchKernelGGL(reduce_slabs_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, out, n, (int)S);

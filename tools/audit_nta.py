@@ -20,7 +20,7 @@ def audit(path):
     kernel, in_asm = None, False
     agpr = re.compile(r"(?<![\w.])a\[?\d+")
     for ln, line in enumerate(txt, 1):
-        m = re.match(r"^(_ZN\S*gemm_nta_kernel\S*):", line)
+        m = re.match(r"^(_ZN\S*gemm_[nt][nt]a_kernel\S*):", line)
         if m:
             kernel = m.group(1)
             in_asm = False
@@ -47,7 +47,7 @@ def audit(path):
             problems.append(f"{path}:{ln}: compiler-generated v_accvgpr_write in {kernel}: {code}")
     # metadata
     meta = "\n".join(txt)
-    for m in re.finditer(r"\.name:\s+(\S*gemm_nta_kernel\S*)\n(.*?)\.wavefront_size", meta, re.S):
+    for m in re.finditer(r"\.name:\s+(\S*gemm_[nt][nt]a_kernel\S*)\n(.*?)\.wavefront_size", meta, re.S):
         name, body = m.group(1), m.group(2)
         for key in ("private_segment_fixed_size", "vgpr_spill_count"):
             v = re.search(rf"\.{key}:\s+(\d+)", body)

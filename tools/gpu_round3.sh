@@ -21,6 +21,8 @@ for s in $STAGES; do
       timeout 600 python bench.py --shapes --steps 3 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 > gpurun_out/benchq.log 2>&1; echo "rc=$?" >> gpurun_out/benchq.log ;;
     gemmab)
       timeout 600 ./tools/probes/gemm_nta_ab ${GEMMAB_ARGS:-} > gpurun_out/gemm_nt_asm_ab.log 2>&1; echo "rc=$?" >> gpurun_out/gemm_nt_asm_ab.log ;;
+    tnab)
+      timeout 600 ./tools/probes/gemm_tna_ab ${GEMMAB_ARGS:-} > gpurun_out/gemm_tna_ab.log 2>&1; echo "rc=$?" >> gpurun_out/gemm_tna_ab.log ;;
     smoke)
       timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "rc=$?" >> gpurun_out/smoke.log ;;
     stats)
