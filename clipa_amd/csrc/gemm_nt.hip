@@ -306,6 +306,7 @@ int ensure_nt_attrs(int dev) {
 
 std::atomic<int> g_nt_variant{0};
 std::atomic<int> g_abl{0};
+std::atomic<int> g_last_gemm{0};
 
 int current_device(int* dev) {
   const hipError_t e = hipGetDevice(dev);
@@ -335,6 +336,8 @@ extern "C" int clipa_debug_set(int gemm_nt_variant, int ablation_flags) {
   return CLIPA_OK;
 }
 
+extern "C" int clipa_debug_last_gemm(void) { return g_last_gemm.load(std::memory_order_relaxed); }
+
 extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, const float* bias,
                              const void* aux, int64_t M, int64_t N, int64_t K, int64_t lda,
                              int64_t ldb, int64_t ldc, int64_t ldaux, float alpha, int epi, int act,
@@ -361,6 +364,7 @@ extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, co
   // kernel with the hand-scheduled main loop (gemm_nta.hip); bit-identical outputs.  clipa_debug_set(1, .) keeps them on
   // gemm_nt2, clipa_debug_set(2 + s, .) selects generated schedule s (A/B harnesses)
   const int variant = g_nt_variant.load(std::memory_order_relaxed);
+  g_last_gemm.store(1, std::memory_order_relaxed);
   if (variant != 1 && !(a.abl & 13) && nta_eligible(a, out_f32))
     return nta_launch(a, dev, num_cu, variant >= 2 ? variant - 2 : NTA_DEFAULT_SCHEDULE, st);
   const long tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);

@@ -469,6 +469,7 @@ extern "C" int clipa_gemm_tn(const void* P, const void* Q, void* out, float* col
   a.M = (int)M; a.R = (int)R; a.C = (int)C; a.ldp = ldp; a.ldq = ldq; a.ldo = C; a.slice_rows = (int)slice_rows;
   a.colsum = colsum_out ? (float*)workspace + S_plan * R * C : nullptr;
   a.nslices = per_xcd ? (int)S_plan : 0;
+  a.abl = abl;
   const long tiles = ((R + 255) / 256) * ((C + 255) / 256);
   // The 16x16x32 kernel (v3) for the image tower's wide-P products (in-proj and c_fc weight gradients) and its
   // 1024 x 1024 out-proj, the ping-pong kernel (v2) elsewhere (c_proj, the text tower) - per-shape winners of
@@ -495,6 +496,7 @@ extern "C" int clipa_gemm_tn(const void* P, const void* Q, void* out, float* col
   }
   if (!launched) {
     const dim3 grid = per_xcd ? dim3((unsigned)(tiles * S_plan), 1) : dim3((unsigned)tiles, (unsigned)S_plan);
+    g_last_gemm.store(use_v3 ? 4 : 3, std::memory_order_relaxed);
     if (use_v3) hipLaunchKernelGGL(gemm_tn3_kernel, grid, dim3(NTHREADS), 2 * STAGE_BYTES, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(gemm_tn2_kernel, grid, dim3(NTHREADS), 2 * STAGE_BYTES, (hipStream_t)stream, a);
     if (int rc = clipa_check_launch("gemm_tn")) return rc;

@@ -45,8 +45,8 @@ __device__ __forceinline__ void tna_store_all(float* o, long ldo, std::integer_s
 }
 
 #define TNA_INPUTS                                                                                                          \
-  [vP] "v"(vP), [vQ] "v"(vQ), [vPe] "v"(vPe), [vPo] "v"(vPo), [vQe] "v"(vQe), [vQo] "v"(vQo), [curP] "s"(curP),             \
-  [curQ] "s"(curQ), [nulP] "s"(nul), [nulQ] "s"(nul), [sP16] "s"(sP16), [sQ16] "s"(sQ16), [sP64] "s"(sP64),                 \
+  [vP] "v"(vP), [vQ] "v"(vQ), [vPe] "v"(vPe), [vPo] "v"(vPo), [vQe] "v"(vQe), [vQo] "v"(vQo), [curP] "s"(useP),             \
+  [curQ] "s"(useQ), [nulP] "s"(nul), [nulQ] "s"(nul), [sP16] "s"(sP16), [sQ16] "s"(sQ16), [sP64] "s"(sP64),                 \
   [sQ64] "s"(sQ64), [ldsw] "s"(ldsw), [nloop] "s"(nloop)
 
 template <int SCHED>
@@ -81,6 +81,10 @@ __global__ __launch_bounds__(TNA_THREADS) void gemm_tna_kernel(TNArgs p) {
   const u32x4 curP = make_srd(p.P + ((size_t)mbeg * p.ldp + r0) * 2, (unsigned)min((long)0xffffff00L, (long)rows * p.ldp * 2));
   const u32x4 curQ = make_srd(p.Q + ((size_t)mbeg * p.ldq + c0) * 2, (unsigned)min((long)0xffffff00L, (long)rows * p.ldq * 2));
   const u32x4 nul = make_srd(p.P, 0u);
+  // ablations (clipa_debug_set flags; wrong results): 65536 = operands never fetched (the LDS-DMA write zeros: LDS traffic
+  // without L2 traffic), 131072 = every K step re-reads the slice's first 64 rows (operand bytes stay L2-resident)
+  const int abl = p.abl;
+  const u32x4 useP = (abl & 65536) ? nul : curP, useQ = (abl & 65536) ? nul : curQ;
 
   // per-lane constants (gen_gemm_tna.py: register map)
   const unsigned smem_base = (unsigned)(size_t)LDS_PTR(smem);
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(TNA_THREADS) void gemm_tna_kernel(TNArgs p) {
   const unsigned vPe = (unsigned)(rb * (int)p.ldp * 2 + ch * 16), vPo = (unsigned)((rb + 8) * (int)p.ldp * 2 + (ch ^ 2) * 16);
   const unsigned vQe = (unsigned)(rb * (int)p.ldq * 2 + ch * 16), vQo = (unsigned)((rb + 8) * (int)p.ldq * 2 + (ch ^ 2) * 16);
   const unsigned sP16 = (unsigned)(32 * p.ldp), sQ16 = (unsigned)(32 * p.ldq);     // bytes per 16 rows
-  const unsigned sP64 = (unsigned)(128 * p.ldp), sQ64 = (unsigned)(128 * p.ldq);   // bytes per K step (64 rows)
+  const unsigned sP64 = (abl & 131072) ? 0u : (unsigned)(128 * p.ldp), sQ64 = (abl & 131072) ? 0u : (unsigned)(128 * p.ldq);   // bytes per K step (64 rows)
   const unsigned ldsw = (unsigned)__builtin_amdgcn_readfirstlane((int)(smem_base + wave * 1024));
   const unsigned nloop = (unsigned)(nmt / 2 - 2);
 
@@ -159,6 +163,7 @@ int tna_launch(const TNArgs& a, int dev, dim3 grid, int sched, hipStream_t st) {
     }
   });
   if (g_tna_rc[dev]) return g_tna_rc[dev];
+  g_last_gemm.store(5, std::memory_order_relaxed);
   if (sched == 1) hipLaunchKernelGGL(gemm_tna_kernel<1>, grid, dim3(TNA_THREADS), TNA_LDS, st, a);
   else hipLaunchKernelGGL(gemm_tna_kernel<0>, grid, dim3(TNA_THREADS), TNA_LDS, st, a);
   return clipa_check_launch("gemm_tna");

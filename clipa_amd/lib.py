@@ -19,6 +19,7 @@ SIGNATURES = {
     "clipa_last_error": (_c.c_char_p, []),
     "clipa_version": (_I32, []),
     "clipa_debug_set": (_I32, [_I32, _I32]),
+    "clipa_debug_last_gemm": (_I32, []),
     "clipa_gemm_nt": (_I32, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I32, _I32, _I32, _P]),
     "clipa_gemm_tn_workspace": (_I64, [_I64, _I64, _I64, _c.POINTER(_I64)]),
     "clipa_gemm_tn": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I32, _P, _I64, _P]),

@@ -98,8 +98,8 @@ int main(int argc, char** argv) {
         CK(hipMemcpyAsync(md, d_md, 8, hipMemcpyDeviceToHost, st));
         CK(hipStreamSynchronize(st));
       }
-      printf("{\"check\": \"values\", \"M\": %ld, \"R\": %ld, \"C\": %ld, \"variant\": %d, \"nan\": %d, \"worst_rel_err_vs_fp64\": %.3g, \"worst_colsum_rel_err\": %.3g, \"max_abs_diff_vs_old\": %.3g, \"max_abs\": %.3g}\n",
-             M, R, C, v, nan, worst, worst_cs, md[0], md[1]);
+      printf("{\"check\": \"values\", \"kernel\": %d, \"M\": %ld, \"R\": %ld, \"C\": %ld, \"variant\": %d, \"nan\": %d, \"worst_rel_err_vs_fp64\": %.3g, \"worst_colsum_rel_err\": %.3g, \"max_abs_diff_vs_old\": %.3g, \"max_abs\": %.3g}\n",
+             clipa_debug_last_gemm(), M, R, C, v, nan, worst, worst_cs, md[0], md[1]);
       fflush(stdout);
     }
     if (M >= 50000) {
@@ -125,6 +125,27 @@ int main(int argc, char** argv) {
         printf(", \"v%d_ms\": %.4f, \"v%d_tflops\": %.1f", v, med, v, 2.0 * M * R * C / (med * 1e-3) / 1e12);
       }
       printf("}\n");
+      fflush(stdout);
+      // memory ablations of gemm_tna (wrong results): operands never fetched / every step re-reads the same 64 rows
+      const int ab[3] = {0, 65536, 131072};
+      printf("{\"check\": \"ablation\", \"M\": %ld, \"R\": %ld, \"C\": %ld", M, R, C);
+      for (int a = 0; a < 3; ++a) {
+        std::vector<float> tt;
+        for (int r = 0; r < 3; ++r) {
+          clipa_debug_set(0, ab[a]);
+          clipa_gemm_tn(P, Q, out[1], csum[1], M, R, C, R, C, 0, ws, wsb, st);
+          CK(hipEventRecord(e0, st));
+          for (int k = 0; k < reps; ++k) clipa_gemm_tn(P, Q, out[1], csum[1], M, R, C, R, C, 0, ws, wsb, st);
+          CK(hipEventRecord(e1, st));
+          CK(hipEventSynchronize(e1));
+          float x;
+          CK(hipEventElapsedTime(&x, e0, e1));
+          tt.push_back(x / reps);
+        }
+        std::sort(tt.begin(), tt.end());
+        printf(", \"%s_tflops\": %.1f", a == 0 ? "normal" : a == 1 ? "no_fetch" : "l2_resident", 2.0 * M * R * C / (tt[1] * 1e-3) / 1e12);
+      }
+      printf(", \"kernel\": %d}\n", clipa_debug_last_gemm());
       fflush(stdout);
     }
     CK(hipFree(P)); CK(hipFree(Q)); CK(hipFree(ws));
