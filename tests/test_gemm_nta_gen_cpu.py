@@ -18,14 +18,16 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 def test_inc_is_up_to_date():
     import gen_gemm_nta as G
+    import gen_gemm_tna as T
     assert open(G.OUT).read() == G.render(), "run: python tools/gen_gemm_nta.py"
+    assert open(T.OUT).read() == T.render(), "run: python tools/gen_gemm_tna.py"
 
 
-@pytest.mark.parametrize("sched", [0, 1, 2])
+@pytest.mark.parametrize("sched", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_schedule_ordering_rules(sched):
     import gen_gemm_nta as G
-    S = G.SCHEDULES[sched]
-    lines = G.step_text(S, 0, "cur", False, False, "16", False)
+    S = G.SCHEDULES_ALL[sched]
+    lines = G.step_text(S, 0, "cur", False, False, str(G.younger(S)), False)
     pos = {k: [] for k in ("mfma", "rd", "dma", "m0", "bar", "vm", "lgk")}
     for i, l in enumerate(lines):
         key = ("mfma" if l.startswith("v_mfma") else "rd" if l.startswith("ds_read") else "dma" if l.startswith("buffer_load") else
@@ -36,7 +38,10 @@ def test_schedule_ordering_rules(sched):
     assert len(pos["mfma"]) == 128 and len(pos["rd"]) == 32 and len(pos["dma"]) == 16 and len(pos["bar"]) == 2
     rd1, rd0 = pos["rd"][:16], pos["rd"][16:]
     assert max(rd1) < pos["lgk"][0] < pos["bar"][0] < min(pos["dma"])          # slot freed (all waves) before the DMA re-fills it
-    assert max(pos["dma"]) < pos["vm"][0] < pos["bar"][1] < min(rd0)           # publish: own DMA counted, then barrier, then reads
+    assert pos["vm"][0] < pos["bar"][1] < min(rd0)                             # publish: wait, then barrier, then reads
+    # the publish wait leaves exactly the LDS-DMA this step has issued before it in flight
+    issued = sum(1 for d in pos["dma"] if d < pos["vm"][0])
+    assert lines[pos["vm"][0]] == f"s_waitcnt vmcnt({issued})" and issued == G.younger(S)
     assert max(rd0) < pos["lgk"][1]
     for d, m in zip(pos["dma"], pos["m0"]):                                    # an M0 write needs a wait state before its LDS-DMA
         assert m < d and any(m < x < d for x in pos["mfma"])
@@ -61,3 +66,35 @@ def test_isa_audit(tmp_path):
     a = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_nta.py"), str(asm)], capture_output=True, text=True)
     assert a.returncode == 0, a.stdout[-3000:]
     assert len(re.findall(r"\.name:\s+\S*gemm_nta_kernel", asm.read_text())) == 15
+
+
+@pytest.mark.parametrize("sched", [0, 1])
+def test_tn_schedule_ordering_rules(sched):
+    """gemm_tna: same rules, plus the slot flip of the fragment-read addresses sits between this step's reads and the read-ahead."""
+    import gen_gemm_nta as G
+    import gen_gemm_tna as T
+    S = T.SCHEDULES[sched]
+    lines = T.step_text(S, 0, "cur", False, False, str(G.younger(S)), True)
+    idx = lambda pred: [i for i, l in enumerate(lines) if pred(l)]
+    mf = idx(lambda l: l.startswith("v_mfma") and "%[cs" not in l)
+    rd, dma, bar = idx(lambda l: l.startswith("ds_read_b64_tr_b16")), idx(lambda l: l.startswith("buffer_load")), idx(lambda l: l == "s_barrier")
+    flip, vm = idx(lambda l: l.startswith("v_xor_b32")), idx(lambda l: l.startswith("s_waitcnt vmcnt"))
+    assert len(mf) == 128 and len(rd) == 64 and len(dma) == 16 and len(bar) == 2 and len(flip) == 16
+    assert len(idx(lambda l: "%[cs" in l)) == 16                                 # P^T . ones: one MFMA per P block and k-half
+    rd1, rd0 = rd[:32], rd[32:]
+    assert max(rd1) < bar[0] < min(dma) and bar[0] < min(flip) and max(flip) < vm[0] < bar[1] < min(rd0)
+    assert min(rd0) > mf[63]
+    issued = sum(1 for d in dma if d < vm[0])
+    assert lines[vm[0]] == f"s_waitcnt vmcnt({issued})"
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason="hipcc not available")
+def test_tn_isa_audit(tmp_path):
+    asm = tmp_path / "gemm_tna.s"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "clipa_amd", "csrc"), "-I",
+           os.path.join(ROOT, "include"), "-Wno-unused-result", "-ffp-contract=fast", "-S", "--cuda-device-only", "-o", str(asm),
+           os.path.join(ROOT, "clipa_amd", "csrc", "gemm_tna.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_nta.py"), str(asm)], capture_output=True, text=True)
+    assert a.returncode == 0, a.stdout[-3000:]

@@ -34,7 +34,7 @@ VADDR_A, VADDR_B = 112, 116                  # + 2 * slot + khalf
 SLOT, IMG, PIECE, BLOCK = 65536, 32768, 4096, 2048
 
 # schedule = issue slots (index of the MFMA after which the instruction is placed; 0..127) of everything that is not an MFMA
-SCHEDULES = {
+SCHEDULES_ALL = {
     # two barriers per step; fragment reads and LDS-DMA one per two MFMAs (the pacing of the vendor's assembly kernel)
     0: dict(rd1_start=0, rd1_stride=2, bar1=34, dma_start=36, dma_stride=2, vmwait=74, rd0_start=76, rd0_stride=2, lgk_end=126),
     # denser front: reads one per MFMA, slot freed at MFMA 20, DMA issued by MFMA 54, operands published later
@@ -52,6 +52,10 @@ SCHEDULES = {
     # early release, DMA one per five MFMAs, publish after the last one
     7: dict(rd1_start=0, rd1_stride=1, bar1=20, dma_start=22, dma_stride=5, vmwait=100, rd0_start=102, rd0_stride=1, lgk_end=126),
 }
+
+
+# the schedules compiled into the library (the rest were A/B'd on hardware: profiles/r03_gemm_nta_schedules_*.jsonl)
+SCHEDULES = {k: SCHEDULES_ALL[k] for k in (0, 3, 4)}
 
 
 def younger(S):
@@ -86,9 +90,16 @@ def step_text(S, slot, srd, first, last, vmcnt, bias):
     m = S["dma_start"]
     assert m > S["bar1"]
     if bias:
+        # last step of the tile: the bias vector and the first 8 residual / pre-activation chunks of the epilogue (rows of
+        # blocks ai = 0, 1; descriptors of 0 bytes when the epilogue has no such operand) are fetched to registers here,
+        # OLDER than the step's 16 LDS-DMA, so that the statement's final vmcnt(16) covers them
         for p in range(4):
             for h in range(2):
                 fill[m - 1 - (p * 2 + h)].append(f"buffer_load_dwordx4 %[bias{p * 2 + h}], %[vbias], %[srdBias], 0 offen offset:{p * 128 + h * 16}")
+        for i in range(8):
+            ai, pp = i // 4, i % 4
+            so = "0" if ai == 0 else "%[saux16]"
+            fill[m - 9 - i].append(f"buffer_load_dwordx4 %[aux{i}], %[vaux], %[srdAux], {so} offen offset:{pp * 64}")
     for q in range(16):
         img, j = q // 8, q % 8
         voff = (VOFF_B if img else VOFF_A) + j

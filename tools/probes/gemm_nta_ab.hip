@@ -43,7 +43,8 @@ int main(int argc, char** argv) {
   struct Shape { long M, N, K; };
   std::vector<Shape> shapes = {{200704, 4096, 1024}, {200704, 1024, 4096}, {200704, 3072, 1024}, {200704, 1024, 1024}, {78848, 768, 3072}, {4096, 512, 256}, {512, 256, 384}};
   if (quick) shapes = {{200704, 4096, 1024}, {200704, 1024, 4096}, {512, 256, 384}};
-  const int NV = 9;   // variant 1 = gemm_nt2, 2..9 = gemm_nta schedule 0..7
+  const int VARS[] = {1, 2, 5, 6};   // clipa_debug_set variant: 1 = gemm_nt2, 2 + s = gemm_nta schedule s (0, 3, 4 are compiled in)
+  const int NV = 4;
   hipStream_t st;
   CK(hipStreamCreate(&st));
   unsigned long long* d_cnt;
@@ -70,7 +71,8 @@ int main(int argc, char** argv) {
       CK(hipMemsetAsync(C[0], 0xff, (size_t)M * N * 2, st));
       run(1, 0);
       CK(hipStreamSynchronize(st));
-      for (int v = 2; v <= NV; ++v) {
+      for (int vi = 1; vi < NV; ++vi) {
+        const int v = VARS[vi];
         CK(hipMemsetAsync(C[1], 0x7f, (size_t)M * N * 2, st));
         if (e.pre) CK(hipMemsetAsync(C2[1], 0x7f, (size_t)M * N * 2, st));
         run(v, 1);
@@ -87,11 +89,12 @@ int main(int argc, char** argv) {
       // ---- timing: interleaved rounds ----
       if (M < 50000) continue;
       const int rounds = quick ? 3 : 5, reps = 3;
-      std::vector<std::vector<float>> ms(NV + 1);
+      std::vector<std::vector<float>> ms(16);
       hipEvent_t e0, e1;
       CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       for (int r = 0; r < rounds; ++r)
-        for (int v = 1; v <= NV; ++v) {
+        for (int vi = 0; vi < NV; ++vi) {
+          const int v = VARS[vi];
           run(v, 1);                                  // warm
           CK(hipEventRecord(e0, st));
           for (int k = 0; k < reps; ++k) run(v, 1);
@@ -102,7 +105,8 @@ int main(int argc, char** argv) {
           ms[v].push_back(t / reps);
         }
       printf("{\"check\": \"time\", \"M\": %ld, \"N\": %ld, \"K\": %ld, \"epi\": \"%s\"", M, N, K, e.name);
-      for (int v = 1; v <= NV; ++v) {
+      for (int vi = 0; vi < NV; ++vi) {
+        const int v = VARS[vi];
         std::sort(ms[v].begin(), ms[v].end());
         const float med = ms[v][ms[v].size() / 2];
         printf(", \"v%d_ms\": %.4f, \"v%d_tflops\": %.1f", v, med, v, 2.0 * M * N * K / (med * 1e-3) / 1e12);
@@ -111,7 +115,8 @@ int main(int argc, char** argv) {
       fflush(stdout);
       if (e.epi == CLIPA_EPI_NONE) {     // main loop only (ablation flag 2): what the epilogues cost on top
         printf("{\"check\": \"mainloop\", \"M\": %ld, \"N\": %ld, \"K\": %ld", M, N, K);
-        for (int v = 1; v <= NV; ++v) {
+        for (int vi = 0; vi < NV; ++vi) {
+          const int v = VARS[vi];
           std::vector<float> t;
           for (int r = 0; r < 3; ++r) {
             clipa_debug_set(v, 2);
