@@ -90,16 +90,13 @@ def step_text(S, slot, srd, first, last, vmcnt, bias):
     m = S["dma_start"]
     assert m > S["bar1"]
     if bias:
-        # last step of the tile: the bias vector and the first 8 residual / pre-activation chunks of the epilogue (rows of
-        # blocks ai = 0, 1; descriptors of 0 bytes when the epilogue has no such operand) are fetched to registers here,
-        # OLDER than the step's 16 LDS-DMA, so that the statement's final vmcnt(16) covers them
+        # last step of the tile: the bias vector is fetched to registers here, OLDER than the step's 16 LDS-DMA, so that the
+        # statement's final vmcnt(16) covers it.  (Fetching the first residual / pre-activation chunks of the epilogue here as
+        # well was measured and changed nothing - profiles/r03_gemm_nta_aux_prefetch_ab.jsonl: those epilogues are bound by
+        # the store path, not by the operand latency.)
         for p in range(4):
             for h in range(2):
                 fill[m - 1 - (p * 2 + h)].append(f"buffer_load_dwordx4 %[bias{p * 2 + h}], %[vbias], %[srdBias], 0 offen offset:{p * 128 + h * 16}")
-        for i in range(8):
-            ai, pp = i // 4, i % 4
-            so = "0" if ai == 0 else "%[saux16]"
-            fill[m - 9 - i].append(f"buffer_load_dwordx4 %[aux{i}], %[vaux], %[srdAux], {so} offen offset:{pp * 64}")
     for q in range(16):
         img, j = q // 8, q % 8
         voff = (VOFF_B if img else VOFF_A) + j
