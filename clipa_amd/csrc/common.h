@@ -53,23 +53,48 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
 // ---- activations (transformer.py:37-40 QuickGELU, nn.GELU erf / tanh) ----------------------
 enum { ACT_GELU_ERF = 0, ACT_GELU_TANH = 1, ACT_QUICK_GELU = 2 };
 
-// erf-GELU on PAIRS of values: the polynomial part compiles to packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32,
-// two elements per VALU slot); only rcp and exp2 stay per element.  q(x) = Phi(-|x|) = 0.5*erfc(|x|/sqrt 2) by
-// Abramowitz-Stegun 7.1.26 / 26.2.17 (|err| <= 0.75e-7, far below bf16 resolution):
-//   q = 0.5 * t*(a1 + t*(a2 + t*(a3 + t*(a4 + t*a5)))) * exp(-x^2/2),  t = 1/(1 + 0.2316419*|x|)
-//   gelu(x)  = x*Phi(x)           = max(x, 0) - |x|*q
-//   gelu'(x) = Phi(x) + x*phi(x)  = (x >= 0 ? 1 - q : q) + x * exp(-x^2/2)/sqrt(2 pi)
+// erf-GELU on PAIRS of values, WITHOUT transcendentals: Phi(x) - 1/2 = erf(x / sqrt 2) / 2 is an odd function, fitted on
+// |x| <= 4.5 as x * P(x^2) (P of degree 9: max |error of x Phi(x)| 5e-5, 8e-6 for |x| < 3; beyond 4.5 the argument is clamped,
+// Phi is clamped to [0, 1] and the error stays below 1e-5 |x| - all far inside the bf16 rounding of the result, which is
+// what every caller stores), and gelu'(x) - 1/2 = erf(x / sqrt 2) / 2 + x phi(x) likewise (degree 10: 2.4e-4 at the clamp
+// edge where gelu' = 1, 1.3e-5 for |x| < 3).  Coefficients: tools/fit_gelu_poly.py.  The epilogues of the fused GEMMs are
+// VALU-bound (profiles/r03_gemm_nta_*.jsonl): ten packed FMAs per pair cost a third of the rcp + exp2 formulation they replace
+// (Abramowitz-Stegun 7.1.26, 2 quarter-rate transcendentals per element).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 gelu_tail2(f32x2 x, f32x2 ax, f32x2& e) {
-  const f32x2 d = ax * 0.2316419f + 1.0f;
-  f32x2 t;
-  t.x = __builtin_amdgcn_rcpf(d.x);
-  t.y = __builtin_amdgcn_rcpf(d.y);
-  const f32x2 u = (x * x) * -0.72134752044448170f;        // -x^2/2 * log2(e)
-  e.x = __builtin_amdgcn_exp2f(u.x);
-  e.y = __builtin_amdgcn_exp2f(u.y);
-  const f32x2 p = ((((0.5307027145f * t - 0.7265760135f) * t + 0.7107068705f) * t - 0.142248368f) * t + 0.127414796f) * t;
-  return p * e;
+__device__ __forceinline__ f32x2 clamp2(f32x2 x, float lo, float hi) {
+  f32x2 r;
+  r.x = __builtin_amdgcn_fmed3f(x.x, lo, hi);
+  r.y = __builtin_amdgcn_fmed3f(x.y, lo, hi);
+  return r;
+}
+__device__ __forceinline__ f32x2 gelu_cdf2(f32x2 x) {        // Phi(x)
+  const f32x2 xc = clamp2(x, -4.5f, 4.5f);
+  const f32x2 t = xc * xc;
+  f32x2 p = t * -1.400016797e-12f + 1.697253120e-10f;
+  p = p * t + -9.193533687e-09f;
+  p = p * t + 2.958848065e-07f;
+  p = p * t + -6.365184678e-06f;
+  p = p * t + 9.787074174e-05f;
+  p = p * t + -1.122675229e-03f;
+  p = p * t + 9.833175198e-03f;
+  p = p * t + -6.633704203e-02f;
+  p = p * t + 3.988837869e-01f;
+  return clamp2(xc * p + 0.5f, 0.0f, 1.0f);
+}
+__device__ __forceinline__ f32x2 gelu_grad2(f32x2 x) {       // Phi(x) + x phi(x)
+  const f32x2 xc = clamp2(x, -4.5f, 4.5f);
+  const f32x2 t = xc * xc;
+  f32x2 p = t * 1.054065974e-12f + -1.329809045e-10f;
+  p = p * t + 7.512951167e-09f;
+  p = p * t + -2.523850424e-07f;
+  p = p * t + 5.655319288e-06f;
+  p = p * t + -8.997389735e-05f;
+  p = p * t + 1.054214113e-03f;
+  p = p * t + -9.228582120e-03f;
+  p = p * t + 5.942921224e-02f;
+  p = p * t + -2.656680481e-01f;
+  p = p * t + 7.978225015e-01f;
+  return xc * p + 0.5f;
 }
 template <int ACT>
 __device__ __forceinline__ float act_fwd(float x);
@@ -78,13 +103,7 @@ __device__ __forceinline__ float act_bwd(float x);
 
 template <int ACT>
 __device__ __forceinline__ f32x2 act_fwd2(f32x2 x) {
-  if (ACT == ACT_GELU_ERF) {
-    const f32x2 ax = {fabsf(x.x), fabsf(x.y)};
-    f32x2 e;
-    const f32x2 q = gelu_tail2(x, ax, e);
-    const f32x2 relu = {fmaxf(x.x, 0.f), fmaxf(x.y, 0.f)};
-    return relu - ax * q;
-  }
+  if (ACT == ACT_GELU_ERF) return x * gelu_cdf2(x);
   f32x2 r;
   r.x = act_fwd<ACT>(x.x);
   r.y = act_fwd<ACT>(x.y);
@@ -92,15 +111,7 @@ __device__ __forceinline__ f32x2 act_fwd2(f32x2 x) {
 }
 template <int ACT>
 __device__ __forceinline__ f32x2 act_bwd2(f32x2 x) {  // d act(x) / dx
-  if (ACT == ACT_GELU_ERF) {
-    const f32x2 ax = {fabsf(x.x), fabsf(x.y)};
-    f32x2 e;
-    const f32x2 q = gelu_tail2(x, ax, e);
-    f32x2 cdf;
-    cdf.x = x.x >= 0.f ? 1.0f - q.x : q.x;
-    cdf.y = x.y >= 0.f ? 1.0f - q.y : q.y;
-    return cdf + x * (e * 0.3989422804014327f);
-  }
+  if (ACT == ACT_GELU_ERF) return gelu_grad2(x);
   f32x2 r;
   r.x = act_bwd<ACT>(x.x);
   r.y = act_bwd<ACT>(x.y);

@@ -244,3 +244,37 @@ def test_lock_image_tower_freezes_the_reference_set(unlocked):
     got = {k: p.requires_grad for k, p in mine.named_parameters()}
     assert got == want
     assert not any(v for k, v in got.items() if k.startswith("visual.conv1"))
+
+
+def test_gelu_polynomials():
+    """The erf-GELU of the kernels (clipa_amd/csrc/common.h: gelu_cdf2 / gelu_grad2) is two odd polynomials, no transcendentals.
+    Their coefficients are parsed from the header and evaluated exactly as the kernel does (fp32 Horner, clamp at 4.5) against
+    scipy's erf: |x Phi(x) - gelu(x)| <= 6e-5 inside the clamp (<= 1e-5 for |x| < 3) and <= 2e-5 |x| beyond it; |gelu'| error
+    <= 3e-4 (<= 2e-5 for |x| < 3) - one to two orders below the bf16 rounding of the values the epilogues store."""
+    import scipy.special as sp
+    sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    import sys
+    sys.path.insert(0, sys_path)
+    import fit_gelu_poly as F
+    src = open(os.path.join(os.path.dirname(sys_path), "clipa_amd", "csrc", "common.h")).read()
+
+    def coefs(fn):
+        body = src[src.index(f"f32x2 {fn}(f32x2 x)"):]
+        body = body[:body.index("return")]
+        first = re.search(r"p = t \* (-?[0-9.e+-]+)f \+ (-?[0-9.e+-]+)f;", body)
+        rest = re.findall(r"p = p \* t \+ (-?[0-9.e+-]+)f;", body)
+        return np.array([float(first.group(1)), float(first.group(2))] + [float(r) for r in rest], dtype=np.float32)
+
+    cf, cb = coefs("gelu_cdf2"), coefs("gelu_grad2")
+    assert len(cf) == 10 and len(cb) == 11
+    xs = np.linspace(-40, 40, 800001).astype(np.float32)
+    x64 = xs.astype(np.float64)
+    gelu = x64 * F.Phi(x64)
+    got = np.float32(xs * F.gelu_cdf32(xs, cf)).astype(np.float64)
+    err = np.abs(got - gelu)
+    inside = np.abs(xs) <= 4.5
+    assert err[inside].max() <= 6e-5 and err[np.abs(xs) < 3].max() <= 1e-5
+    assert (err[~inside] <= 2e-5 * np.abs(x64[~inside])).all()
+    dg = F.Phi(x64) + x64 * F.phi(x64)
+    errb = np.abs(F.gelu_grad32(xs, cb).astype(np.float64) - dg)
+    assert errb.max() <= 3e-4 and errb[np.abs(xs) < 3].max() <= 2e-5
