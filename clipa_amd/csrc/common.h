@@ -67,34 +67,46 @@ __device__ __forceinline__ f32x2 clamp2(f32x2 x, float lo, float hi) {
   r.y = __builtin_amdgcn_fmed3f(x.y, lo, hi);
   return r;
 }
-__device__ __forceinline__ f32x2 gelu_cdf2(f32x2 x) {        // Phi(x)
-  const f32x2 xc = clamp2(x, -4.5f, 4.5f);
-  const f32x2 t = xc * xc;
-  f32x2 p = t * -1.400016797e-12f + 1.697253120e-10f;
-  p = p * t + -9.193533687e-09f;
-  p = p * t + 2.958848065e-07f;
-  p = p * t + -6.365184678e-06f;
-  p = p * t + 9.787074174e-05f;
-  p = p * t + -1.122675229e-03f;
-  p = p * t + 9.833175198e-03f;
-  p = p * t + -6.633704203e-02f;
-  p = p * t + 3.988837869e-01f;
-  return clamp2(xc * p + 0.5f, 0.0f, 1.0f);
+// NP pairs in LOCKSTEP: the Horner chain of one pair is ten dependent packed FMAs (and gfx950 wants a wait state between
+// dependent v_pk_fma_f32), so the pairs of a 16-byte chunk advance together - four independent FMAs per coefficient.
+constexpr float GELU_P[10] = {-1.400016797e-12f, 1.697253120e-10f, -9.193533687e-09f, 2.958848065e-07f, -6.365184678e-06f,
+                              9.787074174e-05f, -1.122675229e-03f, 9.833175198e-03f, -6.633704203e-02f, 3.988837869e-01f};
+constexpr float GELU_Q[11] = {1.054065974e-12f, -1.329809045e-10f, 7.512951167e-09f, -2.523850424e-07f, 5.655319288e-06f,
+                              -8.997389735e-05f, 1.054214113e-03f, -9.228582120e-03f, 5.942921224e-02f, -2.656680481e-01f,
+                              7.978225015e-01f};
+template <int NP>
+__device__ __forceinline__ void gelu_cdf_n(const f32x2 (&x)[NP], f32x2 (&phi)[NP]) {        // Phi(x)
+  f32x2 xc[NP], t[NP], p[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) { xc[i] = clamp2(x[i], -4.5f, 4.5f); t[i] = xc[i] * xc[i]; p[i] = t[i] * GELU_P[0] + GELU_P[1]; }
+#pragma unroll
+  for (int k = 2; k < 10; ++k)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = p[i] * t[i] + GELU_P[k];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) phi[i] = clamp2(xc[i] * p[i] + 0.5f, 0.0f, 1.0f);
 }
-__device__ __forceinline__ f32x2 gelu_grad2(f32x2 x) {       // Phi(x) + x phi(x)
-  const f32x2 xc = clamp2(x, -4.5f, 4.5f);
-  const f32x2 t = xc * xc;
-  f32x2 p = t * 1.054065974e-12f + -1.329809045e-10f;
-  p = p * t + 7.512951167e-09f;
-  p = p * t + -2.523850424e-07f;
-  p = p * t + 5.655319288e-06f;
-  p = p * t + -8.997389735e-05f;
-  p = p * t + 1.054214113e-03f;
-  p = p * t + -9.228582120e-03f;
-  p = p * t + 5.942921224e-02f;
-  p = p * t + -2.656680481e-01f;
-  p = p * t + 7.978225015e-01f;
-  return xc * p + 0.5f;
+template <int NP>
+__device__ __forceinline__ void gelu_grad_n(const f32x2 (&x)[NP], f32x2 (&g)[NP]) {         // Phi(x) + x phi(x)
+  f32x2 xc[NP], t[NP], p[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) { xc[i] = clamp2(x[i], -4.5f, 4.5f); t[i] = xc[i] * xc[i]; p[i] = t[i] * GELU_Q[0] + GELU_Q[1]; }
+#pragma unroll
+  for (int k = 2; k < 11; ++k)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = p[i] * t[i] + GELU_Q[k];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) g[i] = xc[i] * p[i] + 0.5f;
+}
+__device__ __forceinline__ f32x2 gelu_cdf2(f32x2 x) {
+  f32x2 a[1] = {x}, r[1];
+  gelu_cdf_n<1>(a, r);
+  return r[0];
+}
+__device__ __forceinline__ f32x2 gelu_grad2(f32x2 x) {
+  f32x2 a[1] = {x}, r[1];
+  gelu_grad_n<1>(a, r);
+  return r[0];
 }
 template <int ACT>
 __device__ __forceinline__ float act_fwd(float x);

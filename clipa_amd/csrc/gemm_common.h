@@ -49,6 +49,23 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 template <int ACT>
 __device__ __forceinline__ void epi_apply(int epi, float* v, const float* a) {
+  if (ACT == ACT_GELU_ERF) {      // the four pairs of the chunk in lockstep (common.h: gelu_cdf_n)
+    f32x2 x[4], r[4];
+    if (epi == CLIPA_EPI_ACT) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x[i] = f32x2{v[2 * i], v[2 * i + 1]};
+      gelu_cdf_n<4>(x, r);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const f32x2 y = x[i] * r[i]; v[2 * i] = y.x; v[2 * i + 1] = y.y; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x[i] = f32x2{a[2 * i], a[2 * i + 1]};
+      gelu_grad_n<4>(x, r);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const f32x2 y = f32x2{v[2 * i], v[2 * i + 1]} * r[i]; v[2 * i] = y.x; v[2 * i + 1] = y.y; }
+    }
+    return;
+  }
   if (epi == CLIPA_EPI_ACT) {
 #pragma unroll
     for (int i = 0; i < 8; i += 2) {
