@@ -44,39 +44,57 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
     if (ch < nchunks) { ld8<true>(gamma, (size_t)ch * 8, g[c]); ld8<true>(beta, (size_t)ch * 8, bt[c]); }
   }
   const float invD = 1.0f / (float)D;
-  for (long r = wid; r < rows; r += nw) {
-    float v[NCH][8];
-    float s = 0.f;
+  // TWO rows per wave and iteration: both rows' loads are in flight before the first reduction starts (one row of 2 KB per
+  // wave does not cover the HBM latency at 32 waves per CU: 4.3 TB/s; the backward kernel, which has three loads per row in
+  // flight, runs at the roof)
+  for (long r = wid; r < rows; r += 2 * nw) {
+    const long r2 = r + nw;
+    const bool two = r2 < rows;
+    float v[2][NCH][8];
+    float s[2] = {0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + c * 64;
       if (ch < nchunks) {
-        ld8<XF32>(x, (size_t)r * D + (size_t)ch * 8, v[c]);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) s += v[c][i];
+        ld8<XF32>(x, (size_t)r * D + (size_t)ch * 8, v[0][c]);
+        if (two) ld8<XF32>(x, (size_t)r2 * D + (size_t)ch * 8, v[1][c]);
       }
     }
-    const float mean = wave_sum(s) * invD;
-    float ss = 0.f;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int ch = lane + c * 64;
-      if (ch < nchunks) {
+    for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const float d = v[c][i] - mean; ss += d * d; }
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunks && (k == 0 || two)) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) s[k] += v[k][c][i];
+        }
       }
-    }
-    const float rstd = rsqrtf(wave_sum(ss) * invD + eps);
+    const float mean[2] = {wave_sum(s[0]) * invD, wave_sum(s[1]) * invD};
+    float ss[2] = {0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int ch = lane + c * 64;
-      if (ch < nchunks) {
-        float o[8];
+    for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = (v[c][i] - mean) * rstd * g[c][i] + bt[c][i];
-        st8<YF32>(y, (size_t)r * D + (size_t)ch * 8, o);
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunks && (k == 0 || two)) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { const float d = v[k][c][i] - mean[k]; ss[k] += d * d; }
+        }
       }
-    }
+    const float rstd[2] = {rsqrtf(wave_sum(ss[0]) * invD + eps), rsqrtf(wave_sum(ss[1]) * invD + eps)};
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunks && (k == 0 || two)) {
+          float o[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = (v[k][c][i] - mean[k]) * rstd[k] * g[c][i] + bt[c][i];
+          st8<YF32>(y, (size_t)(k ? r2 : r) * D + (size_t)ch * 8, o);
+        }
+      }
   }
 }
 
