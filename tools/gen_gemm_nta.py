@@ -12,9 +12,8 @@ Structure of one tile (256 x 256 outputs, K = 64 * nkt, nkt even >= 4; wave (wm,
   registers  a[0:255]     accumulators, block (bj, ai) at a[4 (8 bj + ai) : +3]   (bj: weight-row block, ai: token-row block)
              v[128:159]   A0 = token-row fragments of k-half 0 (8 x 4 registers)   v[160:191]  A1 (k-half 1)
              v[192:223]   B0 = weight-row fragments of k-half 0                    v[224:255]  B1
-             v[104:111] / v[112:119]  per-lane byte offsets of the 8 A / 8 B LDS-DMA pieces of a K step
-             v[120:123] / v[124:127]  fragment-read addresses: A (slot 0 k0, slot 0 k1, slot 1 k0, slot 1 k1) / B likewise
-             v102, v103               copies of the bias / deferred-store lane offsets (inputs that are read late)
+             v[96:103] / v[104:111]   per-lane byte offsets of the 8 A / 8 B LDS-DMA pieces of a K step
+             v[112:115] / v[116:119]  fragment-read addresses: A (slot 0 k0, slot 0 k1, slot 1 k0, slot 1 k1) / B likewise
   LDS        two ring slots of 64 KiB (A image 256 rows x 128 B at +0, B image at +32 KiB), the production image and swizzle
   pipeline   K step i computes from registers: its k-half-0 fragments were read at the end of step i-1, its k-half-1
              fragments are read under the first MFMAs; barrier 1 (every wave is done reading slot i&1) frees the slot for
@@ -22,14 +21,10 @@ Structure of one tile (256 x 256 outputs, K = 64 * nkt, nkt even >= 4; wave (wm,
              + barrier 2 publish step i+1's operands, whose k-half-0 fragments are read under the last MFMAs.
   tile edge  the last two steps fetch the NEXT tile's first two K steps (other descriptors, k offset 0), so the ring
              never drains; the tile's bias vector is fetched to registers under the last step.
-  stores     a CU's store path moves ~15 B/clk: the 128 KiB of a tile cost ~5 us during which a one-wave-per-SIMD kernel
-             computes nothing.  ND = 12 of the lane's 32 packed 16-byte chunks therefore stay in registers (48: what fits below
-             v102 beside the statement's other operands) and are stored from INSIDE the next tile's steps 0 and 1, one store per
-             20 MFMAs (operands d0..d11 = the previous tile's chunks 20..31, srdCp its C descriptor; a descriptor of 0 bytes
-             for a workgroup's first tile).
-  vmcnt      loads and stores retire in issue order; every publish wait leaves exactly the operations issued after the
-             LAST LDS-DMA of the step it publishes in flight: `vm_counts` derives the immediates from the slot tables, the
-             part the compiler's epilogue contributes (S stores in front of the statement) is a macro argument.
+  (tried)    keeping 12 of a lane's 32 packed output chunks in registers and storing them from inside the next tile's first
+             two K steps, one store per 20 MFMAs, with exact in-order vmcnt accounting (commit 'gemm_nta: 12 of a lane's 32
+             output chunks ...'): bit-identical and 3..5 % SLOWER on every shape - a store issued inside the K loop stalls
+             the matrix pipe as long as one issued after it (profiles/r03_gemm_nta_deferred_stores_ab.jsonl).
 """
 import os
 import sys
@@ -38,11 +33,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "clipa_amd", "csrc", "gemm_nta_asm.inc")
 
 A0, A1, B0, B1 = 128, 160, 192, 224          # fragment register bases
-VBIAS, VDC = 102, 103                        # copies of two "v" inputs that are read late (outputs may alias the inputs)
-VOFF_A, VOFF_B = 104, 112                    # LDS-DMA per-lane offsets
-VADDR_A, VADDR_B = 120, 124                  # + 2 * slot + khalf
-ND = 12                                      # 16-byte output chunks of a tile whose stores are deferred into the NEXT tile's K loop
-STORE_SLOTS = (8, 28, 48, 68, 88, 108)       # ... after these MFMAs of its steps 0 and 1 (one store per 20 MFMAs)
+VOFF_A, VOFF_B = 96, 104                     # LDS-DMA per-lane offsets
+VADDR_A, VADDR_B = 112, 116                  # + 2 * slot + khalf
 SLOT, IMG, PIECE, BLOCK = 65536, 32768, 4096, 2048
 
 # schedule = issue slots (index of the MFMA after which the instruction is placed; 0..127) of everything that is not an MFMA
@@ -84,32 +76,11 @@ def vr(base, i):
     return f"v[{base + 4 * i}:{base + 4 * i + 3}]"
 
 
-def dma_slots(S):
-    return [S["dma_start"] + 1 + q * S["dma_stride"] for q in range(16)]
-
-
-def vm_counts(S):
-    """Immediates of the publish waits of a tile's steps 0..3 and of a plain step, WITHOUT the S stores the epilogue in front
-    of the statement leaves in flight (they are younger than step 1's operands, i.e. they count for step 0's wait only):
-    operations issued after the last LDS-DMA of the previous step + operations of this step in front of its wait."""
-    dma = dma_slots(S)
-    assert not set(dma) & set(STORE_SLOTS) and S["vmwait"] not in STORE_SLOTS
-    k = sum(1 for d in dma if d <= S["vmwait"])
-    before = sum(1 for x in STORE_SLOTS if x < S["vmwait"])
-    after = sum(1 for x in STORE_SLOTS if x > dma[-1])
-    return {0: k + before, 1: after + k + before, 2: after + k, "plain": k}
-
-
-def step_text(S, slot, srd, first, last, vmcnt, bias, stores=None):
+def step_text(S, slot, srd, first, last, vmcnt, bias):
     """One K step.  slot: ring slot it computes from (and re-fills for step + 2).  srd: 'cur' | 'nxt' descriptors of the
     LDS-DMA it issues.  first: accumulators start from 0.  last: last step of the tile (no publish / read-ahead; the
-    bias fetch rides here).  vmcnt: text of the immediate of the publish wait.  stores: deferred chunks (indices into
-    d0..d15) whose stores ride this step, one per STORE_SLOTS entry."""
+    bias fetch rides here).  vmcnt: text of the immediate of the publish wait."""
     fill = {m: [] for m in range(128)}
-    if stores:
-        for slot_m, i in zip(STORE_SLOTS, stores):
-            ai, pp = (32 - ND + i) // 4, (32 - ND + i) % 4          # chunk 16 + i of the tile: rows of block ai, features 32 pp ..
-            fill[slot_m].append(f"buffer_store_dwordx4 %[d{i}], v{VDC}, %[srdCp], %[sd{ai}] offen offset:{pp * 64}")
     # k-half-1 fragments of THIS step (weights first: their registers were last used earliest in the previous step)
     order = [("B", b) for b in range(8)] + [("A", a) for a in range(8)]
     m = S["rd1_start"]
@@ -129,7 +100,7 @@ def step_text(S, slot, srd, first, last, vmcnt, bias, stores=None):
         # the store path, not by the operand latency.)
         for p in range(4):
             for h in range(2):
-                fill[m - 1 - (p * 2 + h)].append(f"buffer_load_dwordx4 %[bias{p * 2 + h}], v{VBIAS}, %[srdBias], 0 offen offset:{p * 128 + h * 16}")
+                fill[m - 1 - (p * 2 + h)].append(f"buffer_load_dwordx4 %[bias{p * 2 + h}], %[vbias], %[srdBias], 0 offen offset:{p * 128 + h * 16}")
     for q in range(16):
         img, j = q // 8, q % 8
         voff = (VOFF_B if img else VOFF_A) + j
@@ -141,6 +112,8 @@ def step_text(S, slot, srd, first, last, vmcnt, bias, stores=None):
     assert last_dma + 1 < 127
     fill[last_dma + 1].append("s_add_u32 %[sk], %[sk], 128")
     if not last:
+        # step + 1's operands are older than everything this step has issued so far: `younger(S)` LDS-DMA may stay in flight
+        assert vmcnt in ("@VM0@", str(younger(S)))
         fill[S["vmwait"]] += [f"s_waitcnt vmcnt({vmcnt})", "s_barrier"]
         m = S["rd0_start"]
         for kind, b in order:
@@ -160,7 +133,7 @@ def step_text(S, slot, srd, first, last, vmcnt, bias, stores=None):
     return lines
 
 
-def setup_text(tile=True):
+def setup_text():
     """Per-lane addresses from the four "v" inputs (recomputed per statement: nothing of ours lives in registers the
     compiler may touch between statements except the accumulators)."""
     t = ["s_nop 4",
@@ -169,8 +142,6 @@ def setup_text(tile=True):
          f"v_mov_b32 v{VADDR_B}, %[vb]", f"v_xor_b32 v{VADDR_B + 1}, 64, v{VADDR_B}",
          f"v_add_u32 v{VADDR_B + 2}, 0x10000, v{VADDR_B}", f"v_add_u32 v{VADDR_B + 3}, 0x10000, v{VADDR_B + 1}",
          f"v_mov_b32 v{VOFF_A}, %[voffA]", f"v_mov_b32 v{VOFF_B}, %[voffB]"]
-    if tile:
-        t += [f"v_mov_b32 v{VBIAS}, %[vbias]", f"v_mov_b32 v{VDC}, %[vdc]"]
     for j in range(1, 8):
         t.append(f"v_add_u32 v{VOFF_A + j}, %[sA32], v{VOFF_A + j - 1}")
         t.append(f"v_add_u32 v{VOFF_B + j}, %[sB32], v{VOFF_B + j - 1}")
@@ -179,7 +150,7 @@ def setup_text(tile=True):
 
 def prologue_text():
     """Very first tile of a workgroup: fetch its K steps 0 and 1 (32 LDS-DMA per wave)."""
-    t = setup_text(tile=False)
+    t = setup_text()
     for step in range(2):
         t.append(f"s_mov_b32 %[sk], {step * 128}")
         for q in range(16):
@@ -194,7 +165,6 @@ def prologue_text():
 
 def tile_text(S):
     order = [("B", b) for b in range(8)] + [("A", a) for a in range(8)]
-    vm = vm_counts(S)
     t = setup_text()
     t.append("s_mov_b32 %[sk], 256")
     # this tile's step 0 has landed (younger: step 1's 16 LDS-DMA + whatever the epilogue before us left in flight)
@@ -203,10 +173,8 @@ def tile_text(S):
         base, addr = (B0, VADDR_B) if kind == "B" else (A0, VADDR_A)
         t.append(f"ds_read_b128 {vr(base, b)}, v{addr} offset:{b * BLOCK}")
     t.append("s_waitcnt lgkmcnt(0)")
-    k = str(vm["plain"])
-    t += step_text(S, 0, "cur", True, False, "@VM0@", False, stores=range(0, ND // 2))
-    t += step_text(S, 1, "cur", False, False, str(vm[1]), False, stores=range(ND // 2, ND))
-    t += step_text(S, 0, "cur", False, False, str(vm[2]), False)
+    t += step_text(S, 0, "cur", True, False, "@VM0@", False)
+    k = str(younger(S))
     t += step_text(S, 1, "cur", False, False, k, False)
     t += ["s_cmp_eq_u32 %[nloop], 0", "s_cbranch_scc1 NTA_TAIL_%=", "s_mov_b32 %[cnt], %[nloop]", "NTA_LOOP_%=:"]
     t += step_text(S, 0, "cur", False, False, k, False)
@@ -233,7 +201,7 @@ def c_string(lines, indent="  "):
 
 
 def clobbers():
-    regs = [f"v{i}" for i in range(VBIAS, 256)] + [f"a{i}" for i in range(256)]
+    regs = [f"v{i}" for i in range(96, 256)] + [f"a{i}" for i in range(256)]
     out, line = [], "  "
     for r in regs:
         tok = f'"{r}", '
@@ -253,19 +221,18 @@ def render():
     p.append(" \\\n".join(c_string(prologue_text()).split("\n")))
     p.append("")
     for v, S in SCHEDULES.items():
-        vm = vm_counts(S)
+        k = younger(S)
         p.append(f"// schedule {v}: {S}")
-        p.append(f"// publish waits: step 0 = S + {vm[0]}, step 1 = {vm[1]}, step 2 = {vm[2]}, later steps = {vm['plain']}")
-        p.append(f"// VMS: wait in front of the tile's first fragment reads (16 + S: the stores the epilogue in front of the statement")
-        p.append(f"// may leave in flight); VM0: publish wait of the tile's first step.  Both capped at the counter's 63.")
+        p.append(f"// VMS: wait in front of the tile's first fragment reads (16 + stores the epilogue before it may leave in flight);")
+        p.append(f"// VM0: publish wait of the tile's first step ({k} + those stores).  Both capped at the counter's 63.")
         p.append(f"#define NTA_TILE_ASM_{v}(S) NTA_TILE_ASM_{v}_I(NTA_VMS_##S, NTA_VM0_{v}_##S)")
-        for st in (0, 32 - ND, 64 - ND):
-            p.append(f"#define NTA_VM0_{v}_{st} {min(63, vm[0] + st)}")
+        for st in (0, 32, 64):
+            p.append(f"#define NTA_VM0_{v}_{st} {min(63, k + st)}")
         p.append(f"#define NTA_TILE_ASM_{v}_I(VMS, VM0) NTA_TILE_ASM_{v}_II(VMS, VM0)")
         p.append(f"#define NTA_TILE_ASM_{v}_II(VMS, VM0) \\")
         p.append(" \\\n".join(c_string(tile_text(S)).split("\n")))
         p.append("")
-    for st in (0, 32 - ND, 64 - ND):
+    for st in (0, 32, 64):
         p.append(f"#define NTA_VMS_{st} {min(63, 16 + st)}")
     p.append("")
     p.append("#define NTA_CLOBBERS \\")
