@@ -23,6 +23,16 @@ for s in $STAGES; do
       timeout 600 ./tools/probes/gemm_nta_ab ${GEMMAB_ARGS:-} > gpurun_out/gemm_nt_asm_ab.log 2>&1; echo "rc=$?" >> gpurun_out/gemm_nt_asm_ab.log ;;
     tnab)
       timeout 600 ./tools/probes/gemm_tna_ab ${GEMMAB_ARGS:-} > gpurun_out/gemm_tna_ab.log 2>&1; echo "rc=$?" >> gpurun_out/gemm_tna_ab.log ;;
+    fp8conv)
+      timeout 900 python tools/fp8_convergence.py --steps 200 --batch 256 > gpurun_out/fp8_convergence.jsonl 2> gpurun_out/fp8_convergence.err; echo "rc=$?" >> gpurun_out/fp8_convergence.err ;;
+    others)
+      # the other BASELINE configurations on one GPU (builder-run records): B/16 local-only, H/14 bf16 + fp8, L/16 @ 84
+      timeout 400 python bench.py --model ViT-B-16 --steps 3 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 > gpurun_out/bench_b16.log 2>&1
+      for prec in bf16 fp8; do
+        timeout 500 python bench.py --model ViT-H-14 --batch 2048 --precision $prec --steps 2 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 --shapes > gpurun_out/bench_h14_$prec.log 2>&1
+      done
+      timeout 400 python bench.py --model ViT-L-16 --image-size 84 --steps 3 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 > gpurun_out/bench_l16_84.log 2>&1
+      timeout 500 python bench.py --precision fp8 --steps 2 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 > gpurun_out/bench_l16_fp8.log 2>&1 ;;
     smoke)
       timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "rc=$?" >> gpurun_out/smoke.log ;;
     stats)
