@@ -359,13 +359,14 @@ extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, co
   a.M = (int)M; a.N = (int)N; a.K = (int)K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
   a.alpha = alpha; a.epi = epi; a.act = act; a.abl = g_abl.load(std::memory_order_relaxed);
   a.gm = nt_group_size((N + BN - 1) / BN, 256L * K * 2);
+  if ((a.abl >> 20) & 63) a.gm = (a.abl >> 20) & 63;       // experiment: tile-group size override (clipa_debug_set flags bits 20..25)
   hipStream_t st = (hipStream_t)stream;
   // whole-tile bf16 shapes (every block GEMM of the BASELINE configurations at batch multiples of 256) run on the four-wave
   // kernel with the hand-scheduled main loop (gemm_nta.hip); bit-identical outputs.  clipa_debug_set(1, .) keeps them on
   // gemm_nt2, clipa_debug_set(2 + s, .) selects generated schedule s (A/B harnesses)
   const int variant = g_nt_variant.load(std::memory_order_relaxed);
   g_last_gemm.store(1, std::memory_order_relaxed);
-  if (variant != 1 && !(a.abl & 13) && nta_eligible(a, out_f32))
+  if (variant != 1 && !(a.abl & 13 & 0xfffff) && nta_eligible(a, out_f32))
     return nta_launch(a, dev, num_cu, variant >= 2 ? variant - 2 : NTA_DEFAULT_SCHEDULE, st);
   const long tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   if (out_f32) {
