@@ -27,9 +27,9 @@ PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md
 PEAK_FP8_TFLOPS = 5000.0      # dense fp8 peak on v_mfma_f32_16x16x128_f8f6f4 (same guide: ~5 PF dense)
 # the MFMA-bound kernels a step can be dominated by: profile key -> (peak TFLOP/s, description)
 ROOFLINE_KERNELS = {
-    "gemm_nt": (PEAK_BF16_TFLOPS, "gemm_nt (gemm_nt2_kernel<bf16, M16, EPI, PRE>, all epilogue instantiations: v_mfma_f32_16x16x32_bf16, 256x256x64 tile)"),
+    "gemm_nt": (PEAK_BF16_TFLOPS, "gemm_nt (gemm_nta_kernel<EPI, PRE, SCHED>: 4 waves x 512 registers, hand-scheduled v_mfma_f32_16x16x32_bf16 main loop, 256x256x64 tile, all epilogue instantiations; gemm_nt2_kernel on ragged shapes)"),
     "gemm_nt_f8": (PEAK_FP8_TFLOPS, "gemm_nt_f8 (gemm_nt_f8_kernel: v_mfma_f32_16x16x128_f8f6f4, 256x256x128 tile)"),
-    "gemm_tn": (PEAK_BF16_TFLOPS, "gemm_tn (gemm_tn2 / gemm_tn3: bf16 weight-gradient GEMM, 256x256 tile, split-M)"),
+    "gemm_tn": (PEAK_BF16_TFLOPS, "gemm_tn (gemm_tna_kernel: hand-scheduled bf16 weight-gradient GEMM, 256x256 tile, split-M; gemm_tn2 / gemm_tn3 on ragged shapes)"),
 }
 
 
