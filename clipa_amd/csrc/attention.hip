@@ -119,6 +119,36 @@ __device__ __forceinline__ void store_frag_T(char* base, long ld, long row, int 
   }
 }
 
+// The same tile (head dim 64: both 32-column fragments of a 32-row tile = 32 rows of 128 B) stored as WHOLE 128-byte rows:
+// store_frag_T writes 8 bytes per lane to 32 different rows per instruction (16 instructions, every one touching 32 cache
+// lines); here the tile passes through 4 KB of LDS private to the wave (16-byte chunks XOR-swizzled by the row, conflict-free
+// both ways) and leaves as 4 instructions of 8 full rows each.  The global stores of the backward cost 21 % of its time
+// in the scattered form (profiles/r03_attention_bwd_ablations.jsonl).
+__device__ __forceinline__ void store_tile64(char* stage, char* base, long ld, long row0, int rows_valid, int col0, int lane,
+                                             const f32x16& a0, const f32x16& a1, float mul) {
+  const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+    const f32x16& a = dt ? a1 : a0;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      u32x2 w;
+      w[0] = pack2bf(a[4 * qd + 0] * mul, a[4 * qd + 1] * mul);
+      w[1] = pack2bf(a[4 * qd + 2] * mul, a[4 * qd + 3] * mul);
+      *(u32x2*)(stage + l31 * 128 + (((4 * dt + qd) ^ (l31 & 7)) << 4) + 8 * hi) = w;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // one wave: LDS operations retire in order, only the compiler needs telling
+  const int chunk = lane & 7;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 8 * j + (lane >> 3);
+    const u32x4 v = *(const u32x4*)(stage + row * 128 + ((chunk ^ (row & 7)) << 4));
+    if (row < rows_valid) *(u32x4*)(base + ((row0 + row) * ld + col0) * 2 + chunk * 16) = v;
+  }
+  asm volatile("" ::: "memory");
+}
+
 // Row softmax over the transposed score fragments of one 32-query tile.  In: raw q.k scores.  Out: s =
 // exp2(c*(s - rowmax)) (un-normalised, c = scale*log2 e folded into one FMA), inv = 1/rowsum, m2 = c*rowmax.
 // key(kt, r) = 32kt + 8(r>>2) + (r&3) + 4hi is valid iff < lim (padding / causal bound); tiles valid for
@@ -164,6 +194,16 @@ __device__ __forceinline__ void load_frags(const __amdgpu_buffer_rsrc_t rs, long
     f[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(row * ld * 2 + (2 * ks + hi) * 16), 0, 0));
 }
 
+// whole-row stores (store_tile64) need 16 KB of LDS more per workgroup: taken where the workgroups per CU stay what they are
+template <int NKT, int DH>
+__host__ __device__ constexpr bool fwd_stages() {
+  return DH == 64 && (WGHeads<NKT>::HPW * 2 * NKT * 32 * HD<DH>::RB + 16384) * HD<DH>::WGS <= 160 * 1024;
+}
+template <int NKT, int DH>
+__host__ __device__ constexpr bool bwd_stages() {
+  return DH == 64 && (WGHeads<NKT>::HPW * (2 * NKT * 32 * HD<DH>::RB + 3 * NKT * 32 * 4) + 16384) * HD<DH>::WGS <= 160 * 1024;
+}
+
 template <int NKT, int DH, bool CAUSAL>
 __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_fwd_kernel(AttnArgs p) {
   constexpr int LP = NKT * 32, RB = HD<DH>::RB, KS = HD<DH>::KS, DT = HD<DH>::DT;
@@ -174,6 +214,8 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_fwd_kernel(AttnArgs p) 
   const int slot = wave_wg / WPH, wave = wave_wg % WPH;          // head slot of this wave, wave index within the head
   char* sK = smem + slot * (2 * LP * RB);
   char* sV = sK + LP * RB;
+  constexpr bool STAGE = fwd_stages<NKT, DH>();                  // whole-row stores through 4 KB of LDS per wave
+  char* stage = smem + HPW * (2 * LP * RB) + wave_wg * 4096;
   const int l31 = lane & 31, hi = lane >> 5, q16 = (lane >> 4) & 1, i16 = lane & 15;
   const long nheads = (long)p.B * p.H;
   const long head_raw = (long)blockIdx.x * HPW + slot;
@@ -239,7 +281,10 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_fwd_kernel(AttnArgs p) 
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans<DH>(sV, 32 * kt + 16 * s2, 32 * dt, hi, q16, i16), pf, o[dt], 0, 0, 0);
       }
     }
-    if (qg < p.L && live) {
+    if constexpr (STAGE) {
+      if (live) store_tile64(stage, p.o, p.ld_o, (long)b * p.L + 32 * qt, p.L - 32 * qt, h * DH, lane, o[0], o[1], inv);
+      if (qg < p.L && live && p.stats && hi == 0) *(float2*)(p.stats + ((size_t)head * p.L + qg) * 2) = make_float2(m2, inv);
+    } else if (qg < p.L && live) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
         store_frag_T(p.o, p.ld_o, (long)b * p.L + qg, h * DH + 32 * dt, hi, o[dt], inv, DH - 32 * dt);
@@ -268,6 +313,8 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
   float* sM = (float*)(img0 + 2 * LP * RB);
   float* sL = sM + LP;
   float* sD = sL + LP;
+  constexpr bool STAGE = bwd_stages<NKT, DH>();                  // whole-row stores through 4 KB of LDS per wave
+  char* stage = smem + HPW * (2 * LP * RB + 3 * LP * 4) + wave_wg * 4096;
   const int l31 = lane & 31, hi = lane >> 5, q16 = (lane >> 4) & 1, i16 = lane & 15;
   const long nheads = (long)p.B * p.H;
   const long head_raw = (long)blockIdx.x * HPW + slot;
@@ -346,7 +393,9 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
           dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans<DH>(img0, 32 * kt + 16 * s2, 32 * dt, hi, q16, i16), dsf, dq[dt], 0, 0, 0);
       }
     }
-    if (qg < p.L && live) {
+    if constexpr (STAGE) {
+      if (live) store_tile64(stage, p.dq, p.ld_dqkv, (long)b * p.L + 32 * qt, p.L - 32 * qt, h * DH, lane, dq[0], dq[1], 1.0f);
+    } else if (qg < p.L && live) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
         store_frag_T(p.dq, p.ld_dqkv, (long)b * p.L + qg, h * DH + 32 * dt, hi, dq[dt], 1.0f, DH - 32 * dt);
@@ -415,7 +464,12 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
         }
       }
     }
-    if (kg < p.L && live) {
+    if constexpr (STAGE) {
+      if (live) {
+        store_tile64(stage, p.dk, p.ld_dqkv, (long)b * p.L + 32 * kt, p.L - 32 * kt, h * DH, lane, dk[0], dk[1], 1.0f);
+        store_tile64(stage, p.dv, p.ld_dqkv, (long)b * p.L + 32 * kt, p.L - 32 * kt, h * DH, lane, dv[0], dv[1], 1.0f);
+      }
+    } else if (kg < p.L && live) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         store_frag_T(p.dk, p.ld_dqkv, (long)b * p.L + kg, h * DH + 32 * dt, hi, dk[dt], 1.0f, DH - 32 * dt);
@@ -719,7 +773,7 @@ constexpr int ATTN_MAX_DEVICES = 64;
 template <int NKT, int DH, bool CAUSAL>
 int launch_fwd_c(const AttnArgs& a, hipStream_t st) {
   constexpr int HPW = WGHeads<NKT>::HPW;
-  const int lds = HPW * 2 * NKT * 32 * HD<DH>::RB;
+  const int lds = HPW * 2 * NKT * 32 * HD<DH>::RB + (fwd_stages<NKT, DH>() ? 16384 : 0);
   // the LDS opt-in is a per-device function attribute: once per (kernel instantiation, device), thread-safe (the
   // forward runs on the Python main thread, the backward on autograd's worker thread)
   static std::once_flag once[ATTN_MAX_DEVICES];
@@ -742,7 +796,7 @@ int launch_fwd(const AttnArgs& a, hipStream_t st) {
 template <int NKT, int DH, bool CAUSAL>
 int launch_bwd_c(const AttnArgs& a, hipStream_t st) {
   constexpr int HPW = WGHeads<NKT>::HPW;
-  const int lds = HPW * (2 * NKT * 32 * HD<DH>::RB + 3 * NKT * 32 * 4);
+  const int lds = HPW * (2 * NKT * 32 * HD<DH>::RB + 3 * NKT * 32 * 4) + (bwd_stages<NKT, DH>() ? 16384 : 0);
   // the LDS opt-in is a per-device function attribute: once per (kernel instantiation, device), thread-safe (the
   // forward runs on the Python main thread, the backward on autograd's worker thread)
   static std::once_flag once[ATTN_MAX_DEVICES];

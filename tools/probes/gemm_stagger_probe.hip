@@ -1,0 +1,50 @@
+// Experiment (not part of the library): workgroups of an XCD started out of phase in gemm_nta_kernel (clipa_debug_set flags
+// bits 4..9: log2(phases) | mode << 3 | scale << 4), at the real launch shapes, M = 806 912.
+// Build:  hipcc --offload-arch=gfx950 -O2 -I include tools/probes/gemm_stagger_probe.hip -o tools/probes/gemm_stagger_probe -Lclipa_amd/lib -lclipa_hip -Wl,-rpath,'$ORIGIN/../../clipa_amd/lib'
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "clipa_hip.h"
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
+__global__ void fill_bf16(unsigned short* p, size_t n, unsigned seed, float scale) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    p[i] = (unsigned short)(__float_as_uint(((h & 0xffffff) * (1.0f / 8388608.0f) - 1.0f) * scale) >> 16);
+  }
+}
+int main() {
+  hipStream_t st; CK(hipStreamCreate(&st));
+  struct Case { long M, N, K; int epi; const char* name; };
+  const Case cases[] = {{806912, 4096, 1024, 0, "bias"}, {806912, 4096, 1024, 1, "gelu"}, {806912, 4096, 1024, 3, "dact"},
+                        {806912, 3072, 1024, 0, "bias"}, {806912, 1024, 4096, 2, "add"}, {806912, 1024, 1024, 2, "add"}};
+  // code = log2(phases) | mode << 3 (0: neighbours differ, 1: blocks of neighbours share a phase) | scale << 4 (0: 1 tile period, 1: 1/2, 2: 1/4, 3: 2)
+  const int codes[] = {0, 4, 8, 0, 4, 8};   // x16: flags 0 / 64 (stores dropped) / 128 (stores hit one tile)
+  for (const Case& s : cases) {
+    unsigned short *A, *B, *C, *aux = nullptr; float* bias;
+    CK(hipMalloc(&A, (size_t)s.M * s.K * 2)); CK(hipMalloc(&B, (size_t)s.N * s.K * 2)); CK(hipMalloc(&C, (size_t)s.M * s.N * 2)); CK(hipMalloc(&bias, s.N * 4));
+    if (s.epi >= 2) { CK(hipMalloc(&aux, (size_t)s.M * s.N * 2)); fill_bf16<<<2048, 256, 0, st>>>(aux, (size_t)s.M * s.N, 3u, 1.0f); }
+    fill_bf16<<<2048, 256, 0, st>>>(A, (size_t)s.M * s.K, 1u, 1.0f); fill_bf16<<<2048, 256, 0, st>>>(B, (size_t)s.N * s.K, 2u, 0.05f);
+    CK(hipMemsetAsync(bias, 0, s.N * 4, st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    printf("{\"M\": %ld, \"N\": %ld, \"K\": %ld, \"epi\": \"%s\"", s.M, s.N, s.K, s.name);
+    for (int code : codes) {
+      std::vector<float> t;
+      for (int r = 0; r < 3; ++r) {
+        clipa_debug_set(0, code << 4);
+        if (clipa_gemm_nt(A, B, C, nullptr, bias, aux, s.M, s.N, s.K, s.K, s.K, s.N, s.N, 1.0f, s.epi, 0, 0, st)) { printf("gemm failed: %s\n", clipa_last_error()); return 3; }
+        CK(hipEventRecord(e0, st));
+        for (int k = 0; k < 2; ++k) clipa_gemm_nt(A, B, C, nullptr, bias, aux, s.M, s.N, s.K, s.K, s.K, s.N, s.N, 1.0f, s.epi, 0, 0, st);
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        float x; CK(hipEventElapsedTime(&x, e0, e1)); t.push_back(x / 2);
+      }
+      std::sort(t.begin(), t.end());
+      printf(", \"s%d\": %.1f", code, 2.0 * s.M * s.N * s.K / (t[1] * 1e-3) / 1e12);
+    }
+    printf(", \"last_gemm\": %d}\n", clipa_debug_last_gemm()); fflush(stdout);
+    CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(bias)); if (aux) CK(hipFree(aux));
+  }
+  clipa_debug_set(0, 0);
+  return 0;
+}
