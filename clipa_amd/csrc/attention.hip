@@ -401,14 +401,21 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
         store_frag_T(p.dq, p.ld_dqkv, (long)b * p.L + qg, h * DH + 32 * dt, hi, dq[dt], 1.0f, DH - 32 * dt);
     }
   }
+  // the wave's first key tile of phase 2 is still in the K / V images: same register layout as the row-wise global load, which
+  // costs 8 instructions of 32 quarter-rows each and a DRAM-latency wait (-6 % at 197 tokens, -17 % at 77:
+  // profiles/r03_attention_bwd_first_key_tile_from_lds_ab.jsonl)
+  bf16x8 fk[KS], fv[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    fk[ks] = frag_direct<DH>(img0, 32 * wave, l31, hi, ks);
+    fv[ks] = frag_direct<DH>(img1, 32 * wave, l31, hi, ks);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();   // everyone is done with the K / V images (and the statistics are in LDS)
 
   // ---- phase 2: dK, dV --------------------------------------------------------------------------
   dma_image<DH>(rsQ, img0, LP, p.ld_qkv, wave, lane, WPH);
   dma_image<DH>(rsDO, img1, LP, p.ld_o, wave, lane, WPH);
-  bf16x8 fk[KS], fv[KS];
-  load_frags<KS>(rsK, p.ld_qkv, 32 * wave + l31, hi, fk);
-  load_frags<KS>(rsV, p.ld_qkv, 32 * wave + l31, hi, fv);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kt = wave; kt < NKT; kt += WPH) {
