@@ -47,22 +47,27 @@ struct TNArgs {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int ACT>
+// LOCK: pairs of the 8-value chunk evaluated in lockstep (common.h: gelu_cdf_n) - 4 = the whole chunk, 2 = two halves where
+// the kernel has no registers to spare (the fp8 GEMM's epilogues)
+template <int ACT, int LOCK = 4>
 __device__ __forceinline__ void epi_apply(int epi, float* v, const float* a) {
-  if (ACT == ACT_GELU_ERF) {      // the four pairs of the chunk in lockstep (common.h: gelu_cdf_n)
-    f32x2 x[4], r[4];
-    if (epi == CLIPA_EPI_ACT) {
+  if (ACT == ACT_GELU_ERF) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) x[i] = f32x2{v[2 * i], v[2 * i + 1]};
-      gelu_cdf_n<4>(x, r);
+    for (int h = 0; h < 4; h += LOCK) {
+      f32x2 x[LOCK], r[LOCK];
+      if (epi == CLIPA_EPI_ACT) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const f32x2 y = x[i] * r[i]; v[2 * i] = y.x; v[2 * i + 1] = y.y; }
-    } else {
+        for (int i = 0; i < LOCK; ++i) x[i] = f32x2{v[2 * (h + i)], v[2 * (h + i) + 1]};
+        gelu_cdf_n<LOCK>(x, r);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) x[i] = f32x2{a[2 * i], a[2 * i + 1]};
-      gelu_grad_n<4>(x, r);
+        for (int i = 0; i < LOCK; ++i) { const f32x2 y = x[i] * r[i]; v[2 * (h + i)] = y.x; v[2 * (h + i) + 1] = y.y; }
+      } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const f32x2 y = f32x2{v[2 * i], v[2 * i + 1]} * r[i]; v[2 * i] = y.x; v[2 * i + 1] = y.y; }
+        for (int i = 0; i < LOCK; ++i) x[i] = f32x2{a[2 * (h + i)], a[2 * (h + i) + 1]};
+        gelu_grad_n<LOCK>(x, r);
+#pragma unroll
+        for (int i = 0; i < LOCK; ++i) { const f32x2 y = f32x2{v[2 * (h + i)], v[2 * (h + i) + 1]} * r[i]; v[2 * (h + i)] = y.x; v[2 * (h + i) + 1] = y.y; }
+      }
     }
     return;
   }
@@ -83,7 +88,7 @@ __device__ __forceinline__ void epi_apply(int epi, float* v, const float* a) {
   }
 }
 
-template <int ACT>
+template <int ACT, int LOCK = 4>
 __device__ __forceinline__ u32x4 epi_chunk(int epi, u32x4 v, u32x4 av) {
   float f[8], a[8];
   unpack8(v, f);
@@ -92,7 +97,7 @@ __device__ __forceinline__ u32x4 epi_chunk(int epi, u32x4 v, u32x4 av) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) f[i] += a[i];
   } else {
-    epi_apply<ACT>(epi, f, a);
+    epi_apply<ACT, LOCK>(epi, f, a);
   }
   return pack8(f);
 }
@@ -266,7 +271,7 @@ __device__ __forceinline__ void window_epilogue(char* cb, const WinOut& o, int t
               }
             }
           } else aj = u32x4{0, 0, 0, 0};
-          if (o.act == ACT_GELU_ERF) v = epi_chunk<ACT_GELU_ERF>(EPI, v, aj);
+          if (o.act == ACT_GELU_ERF) v = epi_chunk<ACT_GELU_ERF, ROLL ? 2 : 4>(EPI, v, aj);
           else if (o.act == ACT_GELU_TANH) v = epi_chunk<ACT_GELU_TANH>(EPI, v, aj);
           else v = epi_chunk<ACT_QUICK_GELU>(EPI, v, aj);
         }

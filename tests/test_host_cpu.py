@@ -247,7 +247,7 @@ def test_lock_image_tower_freezes_the_reference_set(unlocked):
 
 
 def test_gelu_polynomials():
-    """The erf-GELU of the kernels (clipa_amd/csrc/common.h: gelu_cdf2 / gelu_grad2) is two odd polynomials, no transcendentals.
+    """The erf-GELU of the kernels (clipa_amd/csrc/common.h: gelu_cdf_n / gelu_grad_n, coefficient tables GELU_P / GELU_Q) is two odd polynomials, no transcendentals.
     Their coefficients are parsed from the header and evaluated exactly as the kernel does (fp32 Horner, clamp at 4.5) against
     scipy's erf: |x Phi(x) - gelu(x)| <= 6e-5 inside the clamp (<= 1e-5 for |x| < 3) and <= 2e-5 |x| beyond it; |gelu'| error
     <= 3e-4 (<= 2e-5 for |x| < 3) - one to two orders below the bf16 rounding of the values the epilogues store."""
@@ -258,14 +258,11 @@ def test_gelu_polynomials():
     import fit_gelu_poly as F
     src = open(os.path.join(os.path.dirname(sys_path), "clipa_amd", "csrc", "common.h")).read()
 
-    def coefs(fn):
-        body = src[src.index(f"f32x2 {fn}(f32x2 x)"):]
-        body = body[:body.index("return")]
-        first = re.search(r"p = t \* (-?[0-9.e+-]+)f \+ (-?[0-9.e+-]+)f;", body)
-        rest = re.findall(r"p = p \* t \+ (-?[0-9.e+-]+)f;", body)
-        return np.array([float(first.group(1)), float(first.group(2))] + [float(r) for r in rest], dtype=np.float32)
+    def coefs(name):     # constexpr float GELU_P[10] = {...};  (Horner order, highest power of x^2 first)
+        m = re.search(r"constexpr float " + name + r"\[\d+\] = \{([^}]*)\}", src)
+        return np.array([float(t.strip().rstrip("f")) for t in m.group(1).split(",")], dtype=np.float32)
 
-    cf, cb = coefs("gelu_cdf2"), coefs("gelu_grad2")
+    cf, cb = coefs("GELU_P"), coefs("GELU_Q")
     assert len(cf) == 10 and len(cb) == 11
     xs = np.linspace(-40, 40, 800001).astype(np.float32)
     x64 = xs.astype(np.float64)
