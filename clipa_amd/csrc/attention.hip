@@ -149,6 +149,50 @@ __device__ __forceinline__ void store_tile64(char* stage, char* base, long ld, l
   asm volatile("" ::: "memory");
 }
 
+// Head dim 80 (ViT-H/14): rows of 160 bytes = 10 chunks, three 32-column fragments of which the last 16 columns do not exist.
+// Its 256-byte-row images leave 10-13 KB of LDS per workgroup, so the tile goes through the window in two halves of 16 rows
+// (2560 B per wave); 160 = 10 x 16 makes the read side linear in the lane index.
+__device__ __forceinline__ void store_tile80(char* stage, char* base, long ld, long row0, int rows_valid, int col0, int lane,
+                                             const f32x16& a0, const f32x16& a1, const f32x16& a2, float mul) {
+  const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if ((l31 >> 4) == h) {
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt) {
+        const f32x16& a = dt == 0 ? a0 : (dt == 1 ? a1 : a2);
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          if (4 * dt + qd >= 10) continue;
+          u32x2 w;
+          w[0] = pack2bf(a[4 * qd + 0] * mul, a[4 * qd + 1] * mul);
+          w[1] = pack2bf(a[4 * qd + 2] * mul, a[4 * qd + 3] * mul);
+          *(u32x2*)(stage + (l31 & 15) * 160 + (4 * dt + qd) * 16 + 8 * hi) = w;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int task = 64 * j + lane;               // 16 rows x 10 chunks
+      if (task < 160) {
+        const u32x4 v = *(const u32x4*)(stage + task * 16);
+        const int row = task / 10, chunk = task - 10 * row;
+        if (16 * h + row < rows_valid) *(u32x4*)(base + ((row0 + 16 * h + row) * ld + col0) * 2 + chunk * 16) = v;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+template <int DH>
+struct Stg { static constexpr int BYTES = DH == 64 ? 4096 : 2560; };      // LDS window per wave
+template <int DH>
+__device__ __forceinline__ void store_tile(char* stage, char* base, long ld, long row0, int rows_valid, int col0, int lane,
+                                           const f32x16* a, float mul) {
+  if constexpr (DH == 64) store_tile64(stage, base, ld, row0, rows_valid, col0, lane, a[0], a[1], mul);
+  else store_tile80(stage, base, ld, row0, rows_valid, col0, lane, a[0], a[1], a[2], mul);
+}
+
 // Row softmax over the transposed score fragments of one 32-query tile.  In: raw q.k scores.  Out: s =
 // exp2(c*(s - rowmax)) (un-normalised, c = scale*log2 e folded into one FMA), inv = 1/rowsum, m2 = c*rowmax.
 // key(kt, r) = 32kt + 8(r>>2) + (r&3) + 4hi is valid iff < lim (padding / causal bound); tiles valid for
@@ -194,14 +238,14 @@ __device__ __forceinline__ void load_frags(const __amdgpu_buffer_rsrc_t rs, long
     f[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(row * ld * 2 + (2 * ks + hi) * 16), 0, 0));
 }
 
-// whole-row stores (store_tile64) need 16 KB of LDS more per workgroup: taken where the workgroups per CU stay what they are
+// whole-row stores (store_tile) need 16 / 10 KB of LDS more per workgroup: taken where the workgroups per CU stay what they are
 template <int NKT, int DH>
 __host__ __device__ constexpr bool fwd_stages() {
-  return DH == 64 && (WGHeads<NKT>::HPW * 2 * NKT * 32 * HD<DH>::RB + 16384) * HD<DH>::WGS <= 160 * 1024;
+  return (WGHeads<NKT>::HPW * 2 * NKT * 32 * HD<DH>::RB + 4 * Stg<DH>::BYTES) * HD<DH>::WGS <= 160 * 1024;
 }
 template <int NKT, int DH>
 __host__ __device__ constexpr bool bwd_stages() {
-  return DH == 64 && (WGHeads<NKT>::HPW * (2 * NKT * 32 * HD<DH>::RB + 3 * NKT * 32 * 4) + 16384) * HD<DH>::WGS <= 160 * 1024;
+  return (WGHeads<NKT>::HPW * (2 * NKT * 32 * HD<DH>::RB + 3 * NKT * 32 * 4) + 4 * Stg<DH>::BYTES) * HD<DH>::WGS <= 160 * 1024;
 }
 
 template <int NKT, int DH, bool CAUSAL>
@@ -215,7 +259,7 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_fwd_kernel(AttnArgs p) 
   char* sK = smem + slot * (2 * LP * RB);
   char* sV = sK + LP * RB;
   constexpr bool STAGE = fwd_stages<NKT, DH>();                  // whole-row stores through 4 KB of LDS per wave
-  char* stage = smem + HPW * (2 * LP * RB) + wave_wg * 4096;
+  char* stage = smem + HPW * (2 * LP * RB) + wave_wg * Stg<DH>::BYTES;
   const int l31 = lane & 31, hi = lane >> 5, q16 = (lane >> 4) & 1, i16 = lane & 15;
   const long nheads = (long)p.B * p.H;
   const long head_raw = (long)blockIdx.x * HPW + slot;
@@ -282,7 +326,7 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_fwd_kernel(AttnArgs p) 
       }
     }
     if constexpr (STAGE) {
-      if (live) store_tile64(stage, p.o, p.ld_o, (long)b * p.L + 32 * qt, p.L - 32 * qt, h * DH, lane, o[0], o[1], inv);
+      if (live) store_tile<DH>(stage, p.o, p.ld_o, (long)b * p.L + 32 * qt, p.L - 32 * qt, h * DH, lane, o, inv);
       if (qg < p.L && live && p.stats && hi == 0) *(float2*)(p.stats + ((size_t)head * p.L + qg) * 2) = make_float2(m2, inv);
     } else if (qg < p.L && live) {
 #pragma unroll
@@ -314,7 +358,7 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
   float* sL = sM + LP;
   float* sD = sL + LP;
   constexpr bool STAGE = bwd_stages<NKT, DH>();                  // whole-row stores through 4 KB of LDS per wave
-  char* stage = smem + HPW * (2 * LP * RB + 3 * LP * 4) + wave_wg * 4096;
+  char* stage = smem + HPW * (2 * LP * RB + 3 * LP * 4) + wave_wg * Stg<DH>::BYTES;
   const int l31 = lane & 31, hi = lane >> 5, q16 = (lane >> 4) & 1, i16 = lane & 15;
   const long nheads = (long)p.B * p.H;
   const long head_raw = (long)blockIdx.x * HPW + slot;
@@ -394,7 +438,7 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
       }
     }
     if constexpr (STAGE) {
-      if (live) store_tile64(stage, p.dq, p.ld_dqkv, (long)b * p.L + 32 * qt, p.L - 32 * qt, h * DH, lane, dq[0], dq[1], 1.0f);
+      if (live) store_tile<DH>(stage, p.dq, p.ld_dqkv, (long)b * p.L + 32 * qt, p.L - 32 * qt, h * DH, lane, dq, 1.0f);
     } else if (qg < p.L && live) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
@@ -473,8 +517,8 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
     }
     if constexpr (STAGE) {
       if (live) {
-        store_tile64(stage, p.dk, p.ld_dqkv, (long)b * p.L + 32 * kt, p.L - 32 * kt, h * DH, lane, dk[0], dk[1], 1.0f);
-        store_tile64(stage, p.dv, p.ld_dqkv, (long)b * p.L + 32 * kt, p.L - 32 * kt, h * DH, lane, dv[0], dv[1], 1.0f);
+        store_tile<DH>(stage, p.dk, p.ld_dqkv, (long)b * p.L + 32 * kt, p.L - 32 * kt, h * DH, lane, dk, 1.0f);
+        store_tile<DH>(stage, p.dv, p.ld_dqkv, (long)b * p.L + 32 * kt, p.L - 32 * kt, h * DH, lane, dv, 1.0f);
       }
     } else if (kg < p.L && live) {
 #pragma unroll
@@ -780,7 +824,7 @@ constexpr int ATTN_MAX_DEVICES = 64;
 template <int NKT, int DH, bool CAUSAL>
 int launch_fwd_c(const AttnArgs& a, hipStream_t st) {
   constexpr int HPW = WGHeads<NKT>::HPW;
-  const int lds = HPW * 2 * NKT * 32 * HD<DH>::RB + (fwd_stages<NKT, DH>() ? 16384 : 0);
+  const int lds = HPW * 2 * NKT * 32 * HD<DH>::RB + (fwd_stages<NKT, DH>() ? 4 * Stg<DH>::BYTES : 0);
   // the LDS opt-in is a per-device function attribute: once per (kernel instantiation, device), thread-safe (the
   // forward runs on the Python main thread, the backward on autograd's worker thread)
   static std::once_flag once[ATTN_MAX_DEVICES];
@@ -803,7 +847,7 @@ int launch_fwd(const AttnArgs& a, hipStream_t st) {
 template <int NKT, int DH, bool CAUSAL>
 int launch_bwd_c(const AttnArgs& a, hipStream_t st) {
   constexpr int HPW = WGHeads<NKT>::HPW;
-  const int lds = HPW * (2 * NKT * 32 * HD<DH>::RB + 3 * NKT * 32 * 4) + (bwd_stages<NKT, DH>() ? 16384 : 0);
+  const int lds = HPW * (2 * NKT * 32 * HD<DH>::RB + 3 * NKT * 32 * 4) + (bwd_stages<NKT, DH>() ? 4 * Stg<DH>::BYTES : 0);
   // the LDS opt-in is a per-device function attribute: once per (kernel instantiation, device), thread-safe (the
   // forward runs on the Python main thread, the backward on autograd's worker thread)
   static std::once_flag once[ATTN_MAX_DEVICES];

@@ -53,7 +53,8 @@ int main(int argc, char** argv) {
   unsigned long long* cnt; CK(hipMalloc(&cnt, 8));
   struct Shape { long B, H, L, dh; int causal; };
   const Shape shapes[] = {{4096, 16, 197, 64, 0}, {4096, 12, 197, 64, 0}, {4096, 12, 77, 64, 1}, {2048, 16, 257, 80, 0},
-                          {2048, 16, 145, 64, 0}, {4096, 16, 50, 64, 0}, {4096, 8, 32, 64, 1}, {1024, 16, 256, 64, 1}, {512, 16, 200, 64, 0}};
+                          {2048, 16, 145, 64, 0}, {4096, 16, 50, 64, 0}, {4096, 8, 32, 64, 1}, {1024, 16, 256, 64, 1}, {512, 16, 200, 64, 0},
+                          {1024, 16, 50, 80, 0}, {512, 16, 77, 80, 1}, {256, 16, 100, 80, 0}, {256, 16, 26, 80, 0}, {128, 16, 288, 80, 0}};
   for (const Shape& s : shapes) {
     const long D = s.H * s.dh, T = s.B * s.L;
     unsigned short *qkv, *dO; CK(hipMalloc(&qkv, (size_t)T * 3 * D * 2)); CK(hipMalloc(&dO, (size_t)T * D * 2));
