@@ -51,6 +51,11 @@ struct WGHeads {
   static constexpr int HPW = NKT == 1 ? 4 : (NKT == 2 ? 2 : 1);   // heads per workgroup
   static constexpr int WPH = 4 / HPW;                             // waves per head
 };
+// Waves per workgroup.  Head dim 80 with five or more key tiles (ViT-H/14: 257 tokens = 9 tiles) has LDS for ONE workgroup per
+// CU; four waves there leave every SIMD a single wave and nothing to overlap its MFMA -> softmax -> MFMA chain with, so those
+// instantiations run eight waves (two per SIMD, one 32-row tile each for all but one wave).
+template <int NKT, int DH>
+__host__ __device__ constexpr int attn_waves() { return (DH == 80 && NKT >= 5) ? 8 : 4; }
 
 // chunk permutation of an LDS row: conflict-free for both the direct ds_read_b128 operand reads and the
 // transposed ds_read_b64_tr_b16 reads (tools/lds_bank_sim.py) - 8 chunks per 128-B row, 16 per 256-B row
@@ -241,18 +246,18 @@ __device__ __forceinline__ void load_frags(const __amdgpu_buffer_rsrc_t rs, long
 // whole-row stores (store_tile) need 16 / 10 KB of LDS more per workgroup: taken where the workgroups per CU stay what they are
 template <int NKT, int DH>
 __host__ __device__ constexpr bool fwd_stages() {
-  return (WGHeads<NKT>::HPW * 2 * NKT * 32 * HD<DH>::RB + 4 * Stg<DH>::BYTES) * HD<DH>::WGS <= 160 * 1024;
+  return (WGHeads<NKT>::HPW * 2 * NKT * 32 * HD<DH>::RB + attn_waves<NKT, DH>() * Stg<DH>::BYTES) * HD<DH>::WGS <= 160 * 1024;
 }
 template <int NKT, int DH>
 __host__ __device__ constexpr bool bwd_stages() {
-  return (WGHeads<NKT>::HPW * (2 * NKT * 32 * HD<DH>::RB + 3 * NKT * 32 * 4) + 4 * Stg<DH>::BYTES) * HD<DH>::WGS <= 160 * 1024;
+  return (WGHeads<NKT>::HPW * (2 * NKT * 32 * HD<DH>::RB + 3 * NKT * 32 * 4) + attn_waves<NKT, DH>() * Stg<DH>::BYTES) * HD<DH>::WGS <= 160 * 1024;
 }
 
 template <int NKT, int DH, bool CAUSAL>
-__global__ __launch_bounds__(256, HD<DH>::WGS) void attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void attn_fwd_kernel(AttnArgs p) {
   constexpr int LP = NKT * 32, RB = HD<DH>::RB, KS = HD<DH>::KS, DT = HD<DH>::DT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int HPW = WGHeads<NKT>::HPW, WPH = WGHeads<NKT>::WPH;
+  constexpr int HPW = WGHeads<NKT>::HPW, WPH = attn_waves<NKT, DH>() / HPW;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_wg = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int slot = wave_wg / WPH, wave = wave_wg % WPH;          // head slot of this wave, wave index within the head
@@ -345,10 +350,10 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_fwd_kernel(AttnArgs p) 
 // arithmetic, bit-identical results - measured 2-14 % SLOWER on every production shape and was dropped:
 // profiles/r02_attention_bwd_pipelining_ab.jsonl.  The kernel moves ~13 GB per launch; it is not issue-bound.)
 template <int NKT, int DH, bool CAUSAL>
-__global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) {
   constexpr int LP = NKT * 32, RB = HD<DH>::RB, KS = HD<DH>::KS, DT = HD<DH>::DT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int HPW = WGHeads<NKT>::HPW, WPH = WGHeads<NKT>::WPH;
+  constexpr int HPW = WGHeads<NKT>::HPW, WPH = attn_waves<NKT, DH>() / HPW;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_wg = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int slot = wave_wg / WPH, wave = wave_wg % WPH;
@@ -451,8 +456,8 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) 
   bf16x8 fk[KS], fv[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    fk[ks] = frag_direct<DH>(img0, 32 * wave, l31, hi, ks);
-    fv[ks] = frag_direct<DH>(img1, 32 * wave, l31, hi, ks);
+    fk[ks] = frag_direct<DH>(img0, 32 * min(wave, NKT - 1), l31, hi, ks);      // (a wave without a tile reads the last one)
+    fv[ks] = frag_direct<DH>(img1, 32 * min(wave, NKT - 1), l31, hi, ks);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();   // everyone is done with the K / V images (and the statistics are in LDS)
@@ -824,7 +829,7 @@ constexpr int ATTN_MAX_DEVICES = 64;
 template <int NKT, int DH, bool CAUSAL>
 int launch_fwd_c(const AttnArgs& a, hipStream_t st) {
   constexpr int HPW = WGHeads<NKT>::HPW;
-  const int lds = HPW * 2 * NKT * 32 * HD<DH>::RB + (fwd_stages<NKT, DH>() ? 4 * Stg<DH>::BYTES : 0);
+  const int lds = HPW * 2 * NKT * 32 * HD<DH>::RB + (fwd_stages<NKT, DH>() ? attn_waves<NKT, DH>() * Stg<DH>::BYTES : 0);
   // the LDS opt-in is a per-device function attribute: once per (kernel instantiation, device), thread-safe (the
   // forward runs on the Python main thread, the backward on autograd's worker thread)
   static std::once_flag once[ATTN_MAX_DEVICES];
@@ -837,7 +842,7 @@ int launch_fwd_c(const AttnArgs& a, hipStream_t st) {
     if (e != hipSuccess) { clipa_set_error("attn_fwd attr: %s", hipGetErrorString(e)); rc_dev[dev] = CLIPA_ERR_LAUNCH; }
   });
   if (rc_dev[dev]) return rc_dev[dev];
-  hipLaunchKernelGGL((attn_fwd_kernel<NKT, DH, CAUSAL>), dim3((unsigned)(((long)a.B * a.H + HPW - 1) / HPW)), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((attn_fwd_kernel<NKT, DH, CAUSAL>), dim3((unsigned)(((long)a.B * a.H + HPW - 1) / HPW)), dim3(64 * attn_waves<NKT, DH>()), lds, st, a);
   return clipa_check_launch("attn_fwd");
 }
 template <int NKT, int DH>
@@ -847,7 +852,7 @@ int launch_fwd(const AttnArgs& a, hipStream_t st) {
 template <int NKT, int DH, bool CAUSAL>
 int launch_bwd_c(const AttnArgs& a, hipStream_t st) {
   constexpr int HPW = WGHeads<NKT>::HPW;
-  const int lds = HPW * (2 * NKT * 32 * HD<DH>::RB + 3 * NKT * 32 * 4) + (bwd_stages<NKT, DH>() ? 4 * Stg<DH>::BYTES : 0);
+  const int lds = HPW * (2 * NKT * 32 * HD<DH>::RB + 3 * NKT * 32 * 4) + (bwd_stages<NKT, DH>() ? attn_waves<NKT, DH>() * Stg<DH>::BYTES : 0);
   // the LDS opt-in is a per-device function attribute: once per (kernel instantiation, device), thread-safe (the
   // forward runs on the Python main thread, the backward on autograd's worker thread)
   static std::once_flag once[ATTN_MAX_DEVICES];
@@ -860,7 +865,7 @@ int launch_bwd_c(const AttnArgs& a, hipStream_t st) {
     if (e != hipSuccess) { clipa_set_error("attn_bwd attr: %s", hipGetErrorString(e)); rc_dev[dev] = CLIPA_ERR_LAUNCH; }
   });
   if (rc_dev[dev]) return rc_dev[dev];
-  hipLaunchKernelGGL((attn_bwd_kernel<NKT, DH, CAUSAL>), dim3((unsigned)(((long)a.B * a.H + HPW - 1) / HPW)), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((attn_bwd_kernel<NKT, DH, CAUSAL>), dim3((unsigned)(((long)a.B * a.H + HPW - 1) / HPW)), dim3(64 * attn_waves<NKT, DH>()), lds, st, a);
   return clipa_check_launch("attn_bwd");
 }
 template <int NKT, int DH>
