@@ -20,7 +20,7 @@ int main() {
   const Case cases[] = {{806912, 4096, 1024, 0, "bias"}, {806912, 4096, 1024, 1, "gelu"}, {806912, 4096, 1024, 3, "dact"},
                         {806912, 3072, 1024, 0, "bias"}, {806912, 1024, 4096, 2, "add"}, {806912, 1024, 1024, 2, "add"}};
   // code = log2(phases) | mode << 3 (0: neighbours differ, 1: blocks of neighbours share a phase) | scale << 4 (0: 1 tile period, 1: 1/2, 2: 1/4, 3: 2)
-  const int codes[] = {0, 4, 8, 0, 4, 8};   // x16: flags 0 / 64 (stores dropped) / 128 (stores hit one tile)
+  const int codes[] = {0, 16, 0, 16, 4, 20};   // x16: flags 0 / 256 (8 rows x 128 B per store instruction, wrong results) / 64 (stores dropped) / 64+256
   for (const Case& s : cases) {
     unsigned short *A, *B, *C, *aux = nullptr; float* bias;
     CK(hipMalloc(&A, (size_t)s.M * s.K * 2)); CK(hipMalloc(&B, (size_t)s.N * s.K * 2)); CK(hipMalloc(&C, (size_t)s.M * s.N * 2)); CK(hipMalloc(&bias, s.N * 4));
