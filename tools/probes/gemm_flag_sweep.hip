@@ -1,6 +1,9 @@
-// Experiment (not part of the library): workgroups of an XCD started out of phase in gemm_nta_kernel (clipa_debug_set flags
-// bits 4..9: log2(phases) | mode << 3 | scale << 4), at the real launch shapes, M = 806 912.
-// Build:  hipcc --offload-arch=gfx950 -O2 -I include tools/probes/gemm_stagger_probe.hip -o tools/probes/gemm_stagger_probe -Lclipa_amd/lib -lclipa_hip -Wl,-rpath,'$ORIGIN/../../clipa_amd/lib'
+// Experiment harness (not part of the library): clipa_gemm_nt at the real launch shapes (M = 806 912) under a list of
+// clipa_debug_set experiment flags (`codes` x 16).  Flags the library still has: 64 = epilogue stores dropped by the bounds
+// check, 128 = every tile stores to tile 0 (L2 hits).  Round 3 also ran it with kernel-side switches that were removed after
+// the measurement: workgroups of an XCD started out of phase (profiles/r03_gemm_nta_intra_xcd_stagger.jsonl) and 8 rows x
+// 128 B per store instruction (profiles/r03_gemm_nta_store_row_width_timing.jsonl).
+// Build:  hipcc --offload-arch=gfx950 -O2 -I include tools/probes/gemm_flag_sweep.hip -o tools/probes/gemm_flag_sweep -Lclipa_amd/lib -lclipa_hip -Wl,-rpath,'$ORIGIN/../../clipa_amd/lib'
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -20,7 +23,7 @@ int main() {
   const Case cases[] = {{806912, 4096, 1024, 0, "bias"}, {806912, 4096, 1024, 1, "gelu"}, {806912, 4096, 1024, 3, "dact"},
                         {806912, 3072, 1024, 0, "bias"}, {806912, 1024, 4096, 2, "add"}, {806912, 1024, 1024, 2, "add"}};
   // code = log2(phases) | mode << 3 (0: neighbours differ, 1: blocks of neighbours share a phase) | scale << 4 (0: 1 tile period, 1: 1/2, 2: 1/4, 3: 2)
-  const int codes[] = {0, 16, 0, 16, 4, 20};   // x16: flags 0 / 256 (8 rows x 128 B per store instruction, wrong results) / 64 (stores dropped) / 64+256
+  const int codes[] = {0, 4, 8, 0, 4, 8};   // x16: flags 0 / 64 (stores dropped) / 128 (stores hit one tile)
   for (const Case& s : cases) {
     unsigned short *A, *B, *C, *aux = nullptr; float* bias;
     CK(hipMalloc(&A, (size_t)s.M * s.K * 2)); CK(hipMalloc(&B, (size_t)s.N * s.K * 2)); CK(hipMalloc(&C, (size_t)s.M * s.N * 2)); CK(hipMalloc(&bias, s.N * 4));
