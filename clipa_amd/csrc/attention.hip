@@ -354,6 +354,11 @@ __global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void att
   constexpr int LP = NKT * 32, RB = HD<DH>::RB, KS = HD<DH>::KS, DT = HD<DH>::DT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HPW = WGHeads<NKT>::HPW, WPH = attn_waves<NKT, DH>() / HPW;
+  // The eight-wave head-dim-80 instantiations fence hipcc's scheduler between the score MFMAs, the softmax-gradient arithmetic
+  // and the output MFMAs of a pair: left alone it hoists the next group's LDS reads across them and runs 9 % slower
+  // (profiles/r03_attention_bwd_sched_barrier_ab.jsonl; at head dim 64 the same fences move +-2 %, at short head-dim-80
+  // sequences they cost up to 46 %: measured per instantiation, not a rule)
+  constexpr bool FENCE = DH == 80 && NKT >= 5;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_wg = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int slot = wave_wg / WPH, wave = wave_wg % WPH;
@@ -426,6 +431,7 @@ __global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void att
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct<DH>(img0, 32 * kt, l31, hi, ks), fq[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct<DH>(img1, 32 * kt, l31, hi, ks), fdo[ks], dp, 0, 0, 0);
       }
+      if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
       const bool full = CAUSAL ? ((32 * kt + 32 <= p.L) && kt < qt) : (kt < NKT - 1);
       float ds[16];
 #pragma unroll
@@ -434,6 +440,7 @@ __global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void att
         if (!full) pe = (32 * kt + 8 * (r >> 2) + (r & 3) < lim2) ? pe : 0.f;
         ds[r] = pe * (dp[r] - Dq) * p.scale;
       }
+      if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 dsf = pack_frag(ds + 8 * s2);
@@ -488,6 +495,7 @@ __global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void att
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct<DH>(img0, 32 * qt, l31, hi, ks), fk[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct<DH>(img1, 32 * qt, l31, hi, ks), fv[ks], dp, 0, 0, 0);
       }
+      if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
       float pr[16], ds[16];
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
@@ -509,6 +517,7 @@ __global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void att
           ds[r] = pe * (dp[r] - dd[e]) * p.scale;
         }
       }
+      if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 pf = pack_frag(pr + 8 * s2);
