@@ -28,19 +28,23 @@ PEAK_FP8_TFLOPS = 5000.0      # dense fp8 peak on v_mfma_f32_16x16x128_f8f6f4 (s
 # the MFMA-bound kernels a step can be dominated by: profile key -> (peak TFLOP/s, description)
 ROOFLINE_KERNELS = {
     "gemm_nt": (PEAK_BF16_TFLOPS, "gemm_nt (gemm_nta_kernel<EPI, PRE, SCHED>: 4 waves x 512 registers, hand-scheduled v_mfma_f32_16x16x32_bf16 main loop, 256x256x64 tile, all epilogue instantiations; gemm_nt2_kernel on ragged shapes)"),
-    "gemm_nt_f8": (PEAK_FP8_TFLOPS, "gemm_nt_f8 (gemm_nt_f8_kernel: v_mfma_f32_16x16x128_f8f6f4, 256x256x128 tile)"),
+    "gemm_nt_f8": (PEAK_FP8_TFLOPS, "gemm_nt_f8 (gemm_f8a_kernel: 4 waves x 512 registers, hand-scheduled v_mfma_f32_16x16x128_f8f6f4 main loop, 256x256x128 tile; gemm_nt_f8_kernel on ragged shapes)"),
     "gemm_tn": (PEAK_BF16_TFLOPS, "gemm_tn (gemm_tna_kernel: hand-scheduled bf16 weight-gradient GEMM, 256x256 tile, split-M; gemm_tn2 / gemm_tn3 on ragged shapes)"),
 }
 
 
+MEASURED_KERNEL_SOURCES = ("common.h", "gemm_common.h", "gemm_nt.hip", "gemm_nta.hip", "gemm_nta_asm.inc")
+
+
 def kernel_source_sha16():
-    """Identity of the GEMM kernel sources a PMC measurement belongs to (profiles/traffic.json)."""
+    """Identity of the sources of the kernels behind `gemm_nt` launches - what a PMC measurement in profiles/traffic.json
+    belongs to (the fp8 and weight-gradient GEMMs live in other files and do not invalidate it)."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "clipa_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.startswith("gemm_") and os.path.isfile(os.path.join(d, f)):
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in MEASURED_KERNEL_SOURCES:
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 

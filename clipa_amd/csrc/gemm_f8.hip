@@ -14,6 +14,7 @@
 // A lane's 32 operand bytes are chunks g and 4 + g of its row (g = lane >> 4), i.e. the two conflict-free 16-B reads
 // of the bf16 kernel; which k-values a lane holds is immaterial as long as both operands use the same rule.
 #include "gemm_common.h"
+#include "gemm_f8a.h"
 
 namespace clipa_gemm {
 namespace {
@@ -246,6 +247,16 @@ extern "C" int clipa_gemm_nt_f8(const void* A8, const void* B8, const float* sca
   a.alpha = alpha; a.epi = epi; a.act = act; a.abl = g_abl.load(std::memory_order_relaxed);
   a.gm = nt_group_size((N + BN - 1) / BN, 256L * K);
   hipStream_t st = (hipStream_t)stream;
+  // whole-tile shapes with e4m3 weights (every block GEMM of the BASELINE configurations) run on the four-wave kernel with the
+  // hand-scheduled main loop (gemm_f8a.hip); bit-identical outputs.  clipa_debug_set(1, .) keeps them on this file's kernel.
+  if (g_nt_variant.load(std::memory_order_relaxed) != 1 && !(a.abl & 13) && f8a_eligible(M, N, K, fmt_b)) {
+    F8AArgs b;
+    b.A = a.A; b.B = a.B; b.C = a.C; b.C2 = a.C2; b.bias = a.bias; b.aux = a.aux; b.sa = a.sa; b.sb = a.sb;
+    b.M = a.M; b.N = a.N; b.K = a.K; b.lda = a.lda; b.ldb = a.ldb; b.ldc = a.ldc; b.ldaux = a.ldaux;
+    b.alpha = a.alpha; b.epi = a.epi; b.act = a.act; b.abl = a.abl; b.gm = a.gm;
+    return f8a_launch(b, fmt_a, dev, num_cu, st);
+  }
+  g_last_gemm.store(7, std::memory_order_relaxed);
   const long tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   const dim3 grid((unsigned)(tiles < num_cu ? tiles : num_cu)), block(NTHREADS);
 #define LAUNCH_F8(E, P2)                                                                                                   \

@@ -1,0 +1,19 @@
+// Interface between clipa_gemm_nt_f8 (gemm_f8.hip) and the four-wave fp8 kernel (gemm_f8a.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace clipa_gemm {
+
+struct F8AArgs {
+  const char* A; const char* B; char* C; char* C2; const float* bias; const char* aux;
+  const float* sa; const float* sb;     // de-quantisation scales: per row of A [M], per row of B [N]; NULL = 1
+  int M, N, K;                          // K in bytes = fp8 k-values
+  long lda, ldb, ldc, ldaux;            // A, B: bytes; C, aux: elements
+  float alpha;
+  int epi, act, abl, gm;
+};
+
+bool f8a_eligible(long M, long N, long K, int fmt_b);
+int f8a_launch(const F8AArgs& a, int fmt_a, int dev, int num_cu, hipStream_t st);
+
+}  // namespace clipa_gemm

@@ -44,10 +44,11 @@ int clipa_version(void);
  * round-2 gemm_nt experiments live outside the library); flags: gemm_nt 2 = main loop only, 8 = row-major tile order;
  * gemm_tn 1024 / 2048 force the 16x16x32 / ping-pong kernel, 4096 / 8192 force the slice-per-XCD / tile-per-XCD work
  * order, 16384 keeps whole-tile shapes off gemm_tna, 32768 selects its schedule 1; gemm_nt_variant 1 keeps whole-tile shapes
- * on gemm_nt2, 2 + s selects schedule s of gemm_nta.  Production callers never touch it. */
+ * on gemm_nt2 (and whole-tile fp8 shapes on gemm_nt_f8_kernel), 2 + s selects schedule s of gemm_nta; gemm_nta / gemm_f8a 64 = epilogue
+ * stores dropped by the bounds check (gemm_nta), 128 = every tile stores to tile 0.  Production callers never touch it. */
 int clipa_debug_set(int gemm_nt_variant, int ablation_flags);
 /* Which GEMM kernel family the calling process launched last (A/B harnesses and tests check that a shape really ran where
- * they think it did): 0 none, 1 gemm_nt2, 2 gemm_nta, 3 gemm_tn2, 4 gemm_tn3, 5 gemm_tna. */
+ * they think it did): 0 none, 1 gemm_nt2, 2 gemm_nta, 3 gemm_tn2, 4 gemm_tn3, 5 gemm_tna, 6 gemm_f8a, 7 gemm_nt_f8_kernel. */
 int clipa_debug_last_gemm(void);
 
 /* C[M,N] = epi(alpha * A[M,K] . B[N,K]^T + bias[N]); A,B bf16; C bf16 (or f32 when out_f32, epi NONE).
@@ -71,7 +72,8 @@ int clipa_gemm_tn(const void* P, const void* Q, void* out, float* colsum_out, in
  * clipa_quantize_rows: q[r,:] = fp8(x[r,:] * FMAX / max|x[r,:]|) (x bf16, q bytes; fmt 0 = OCP e4m3, FMAX 448; 1 = e5m2,
  * FMAX 57344), dq[r] = max|x[r,:]| / FMAX (1 for an all-zero row).  K % 8 == 0, K <= 8192.
  * clipa_gemm_nt_f8: C = epi(alpha * scale_a[m] * scale_b[n] * A8 . B8^T + bias[n]) on v_mfma_f32_16x16x128_f8f6f4, fp32
- * accumulation, bf16 C / C2 / aux and the epilogues of clipa_gemm_nt; scale_a [M], scale_b [N] may be NULL (= 1).
+ * accumulation, bf16 C / C2 / aux and the epilogues of clipa_gemm_nt; scale_a [M], scale_b [N] may be NULL (= 1).  Whole-tile
+ * shapes (M, N % 256 == 0, K % 256 == 0, K >= 512, e4m3 weights) run on the four-wave kernel of gemm_f8a.hip, bit-identical.
  * K, lda, ldb % 16 == 0 (bytes); N, ldc, ldaux % 8 == 0.
  * clipa_layernorm_fwd_q8: LayerNorm of bf16 rows emitting the e4m3 operand of the next GEMM (q, dq as quantize_rows of
  * the bf16-rounded output) and, when y != NULL, the bf16 output itself. */

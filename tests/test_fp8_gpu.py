@@ -129,6 +129,48 @@ def test_gemm_nt_f8_epilogues(act):
         prev = got
 
 
+def _debug_set(variant, abl):
+    import ctypes
+    from clipa_amd import lib
+    h = lib.load()
+    h.clipa_debug_set.argtypes = [ctypes.c_int, ctypes.c_int]
+    h.clipa_debug_last_gemm.restype = ctypes.c_int
+    assert h.clipa_debug_set(variant, abl) == 0
+    return h
+
+
+@pytest.mark.parametrize("fmt_a", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(512, 256, 768), (1024, 768, 512), (768, 512, 1280)])
+def test_gemm_f8a_matches_gemm_nt_f8(M, N, K, fmt_a):
+    """Whole-tile shapes run on gemm_f8a (four waves, generated main loop, gemm_f8a.hip); every epilogue against the oracle and BIT
+    FOR BIT against gemm_nt_f8_kernel (clipa_debug_set(1, .) keeps that kernel), several tiles per workgroup, both A formats."""
+    o = ops()
+    qa, sa, qb, sb, lin = _f8_operands(M, N, K, fmt_a, 0, seed=31 + fmt_a)
+    bias, aux = rnd(N, seed=8, dtype=f32), rnd(M, N, seed=9)
+    A, SA, B, SB, BIAS, AUX = qa.to(DEV), sa.to(DEV), qb.to(DEV), sb.to(DEV), bias.to(DEV), aux.to(DEV)
+
+    def run():
+        out, pre = o.gemm_nt_f8(A, SA, B, SB, BIAS, epi=o.EPI_ACT, act=0, want_pre=True, fmt_a=fmt_a, alpha=0.75)
+        return (o.gemm_nt_f8(A, SA, B, SB, BIAS, fmt_a=fmt_a, alpha=0.75), out, pre,
+                o.gemm_nt_f8(A, SA, B, SB, BIAS, epi=o.EPI_ACT, act=2, fmt_a=fmt_a, alpha=0.75),
+                o.gemm_nt_f8(A, SA, B, SB, None, epi=o.EPI_ADD, aux=AUX, fmt_a=fmt_a, alpha=0.75),
+                o.gemm_nt_f8(A, None, B, SB, BIAS, epi=o.EPI_DACT, act=0, aux=AUX, fmt_a=fmt_a, alpha=0.75))
+    try:
+        h = _debug_set(1, 0)
+        old = run()
+        assert h.clipa_debug_last_gemm() == 7
+        _debug_set(0, 0)
+        new = run()
+        assert h.clipa_debug_last_gemm() == 6, "the whole-tile shape did not reach gemm_f8a"
+        again = run()
+    finally:
+        _debug_set(0, 0)
+    check("bias", new[0], 0.75 * lin + bias.double(), 2 ** -7, 2e-3)
+    for name, a, b, c in zip(("bias", "gelu", "pre", "quick_gelu", "residual", "gelu_bwd"), old, new, again):
+        assert torch.equal(a, b), f"{name}: gemm_f8a differs from gemm_nt_f8_kernel"
+        assert torch.equal(b, c), f"{name}: second launch differs"
+
+
 def test_gemm_nt_f8_production_rows():
     """M = 806 912 rows (ViT-L/16 @ 224, local batch 4096): the real launch's buffer offsets on sampled rows."""
     o = ops()

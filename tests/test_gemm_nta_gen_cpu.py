@@ -98,3 +98,67 @@ def test_tn_isa_audit(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     a = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_nta.py"), str(asm)], capture_output=True, text=True)
     assert a.returncode == 0, a.stdout[-3000:]
+
+
+def test_f8a_inc_is_up_to_date():
+    import gen_gemm_f8a as F
+    assert open(F.OUT).read() == F.render(), "run: python tools/gen_gemm_f8a.py"
+
+
+def test_f8a_schedule_ordering_rules():
+    """gemm_f8a: a step is 64 MFMAs that each consume a whole block row, so the read-ahead follows the registers: a block is
+    re-loaded only after the last MFMA that reads it, and in front of the first one of the next step that does (counted waits)."""
+    import gen_gemm_f8a as F
+    lines = F.step_text(0, "cur", False, False, "16")
+    idx = lambda pred: [i for i, l in enumerate(lines) if pred(l)]
+    mf, rd, dma = idx(lambda l: l.startswith("v_mfma")), idx(lambda l: l.startswith("ds_read_b128")), idx(lambda l: l.startswith("buffer_load"))
+    m0, bar, vm = idx(lambda l: l.startswith("s_add_u32 m0")), idx(lambda l: l == "s_barrier"), idx(lambda l: l.startswith("s_waitcnt vmcnt"))
+    assert len(mf) == 64 and len(rd) == 32 and len(dma) == 16 and len(bar) == 2 and len(vm) == 1
+    own = rd[:2]                                                        # this step's own B7, read at the top
+    assert max(own) < mf[0] and bar[0] < min(dma) and max(dma) < vm[0] < bar[1] < min(rd[2:])
+    assert lines[vm[0]] == "s_waitcnt vmcnt(16)"                        # all 16 pieces of step + 2 are younger than step + 1's
+    for d, m in zip(dma, m0):
+        assert m < d and any(m < x < d for x in mf)
+    # the slot is freed only after every fragment of the step is in registers: lgkmcnt(0) in front of barrier 1
+    assert lines[bar[0] - 1] == "s_waitcnt lgkmcnt(0)"
+    # write-after-read: a read-ahead into block registers sits behind the last MFMA that names them
+    for i in rd[2:]:
+        lo = int(re.match(r"ds_read_b128 v\[(\d+):", lines[i]).group(1)) // 8 * 8
+        users = [j for j in mf if f"v[{lo}:{lo + 7}]" in lines[j]]
+        assert users and max(users) < i, lines[i]
+    # counted waits in front of the first eight MFMAs: token block m has landed before MFMA m reads it
+    for m in range(8):
+        assert lines[mf[m] - 1] == f"s_waitcnt lgkmcnt({min(15, 16 - 2 * m)})"
+    last = F.step_text(1, "nxt", False, True, None)                     # last step of a tile: no publish, no read-ahead, the vectors ride along
+    assert sum(l.startswith("ds_read_b128") for l in last) == 2 and sum(l == "s_barrier" for l in last) == 1
+    vec = [i for i, l in enumerate(last) if "%[srdVec]" in l]
+    pieces = [i for i, l in enumerate(last) if l.startswith("buffer_load") and "%[srdVec]" not in l]
+    assert len(vec) == 1 and len(pieces) == 16 and vec[0] < min(pieces)     # older than the 16 pieces: the tile's final vmcnt(16) covers it
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason="hipcc not available")
+def test_f8a_isa_audit(tmp_path):
+    asm = tmp_path / "gemm_f8a.s"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "clipa_amd", "csrc"), "-I",
+           os.path.join(ROOT, "include"), "-Wno-unused-result", "-ffp-contract=fast", "-S", "--cuda-device-only", "-o", str(asm),
+           os.path.join(ROOT, "clipa_amd", "csrc", "gemm_f8a.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_nta.py"), str(asm)], capture_output=True, text=True)
+    assert a.returncode == 0, a.stdout[-3000:]
+    assert len(re.findall(r"\.name:\s+\S*gemm_f8a_kernel", asm.read_text())) == 10
+
+
+def test_audit_rejects_a_store_data_race(tmp_path):
+    """The rule gemm_f8a's first hardware run paid for: a VALU write of the third / fourth data register in the slot right
+    behind a 16-byte store."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import audit_nta
+    head = "_ZN10clipa_gemm12_GLOBAL__N_115gemm_f8a_kernelILi0ELb0ELi0EEEvNS_7F8AArgsE:\n"
+    bad = head + "\tbuffer_store_dwordx4 v[6:9], v101, s[40:43], s96 offen\n\tv_pk_mul_f32 v[8:9], v[100:101], v[18:19]\n.Lfunc_end0:\n"
+    ok = head + "\tbuffer_store_dwordx4 v[6:9], v101, s[40:43], s96 offen\n\ts_nop 0\n\tv_pk_mul_f32 v[8:9], v[100:101], v[18:19]\n.Lfunc_end0:\n"
+    ok2 = head + "\tbuffer_store_dwordx4 v[6:9], v101, s[40:43], s96 offen\n\tv_accvgpr_read_b32 v6, a[4]\n.Lfunc_end0:\n"
+    for name, text, n in (("bad", bad, 1), ("ok", ok, 0), ("ok2", ok2, 0)):
+        p = tmp_path / (name + ".s")
+        p.write_text(text)
+        assert len(audit_nta.audit(str(p))) == n, name

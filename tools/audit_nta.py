@@ -7,7 +7,11 @@ touches an accumulation register and never spills (cdna_hip_programming.md 5.7 i
   * no scratch: .private_segment_fixed_size 0, .vgpr_spill_count 0, no scratch_ instructions (SGPR spills into VGPR lanes
     are tolerated: they never touch memory or the accumulation registers);
   * outside ;;#ASMSTART ... ;;#ASMEND no instruction names an AGPR (v_accvgpr_*, a[..] operands);
-  * the kernel gets its 512 registers (accum_offset 256 / agpr_count 256).
+  * the kernel gets its 512 registers (accum_offset 256 / agpr_count 256);
+  * no 12- or 16-byte store is followed IMMEDIATELY by a VALU write (inline asm included) of the third or fourth register of its
+    data: on gfx950 that write wins the race against the store's operand read (observed in gemm_f8a: lanes 12-15 of every 16
+    stored the next chunk's values); the first two registers, or one instruction of distance, are safe (every bit-exact test
+    of gemm_nta exercises them).
 Usage: python tools/audit_nta.py <file.s>   -> exit code 0 / 1, findings on stdout.
 """
 import re
@@ -20,7 +24,7 @@ def audit(path):
     kernel, in_asm = None, False
     agpr = re.compile(r"(?<![\w.])a\[?\d+")
     for ln, line in enumerate(txt, 1):
-        m = re.match(r"^(_ZN\S*gemm_[nt][nt]a_kernel\S*):", line)
+        m = re.match(r"^(_ZN\S*gemm_(?:[nt][nt]a|f8a)_kernel\S*):", line)
         if m:
             kernel = m.group(1)
             in_asm = False
@@ -45,9 +49,35 @@ def audit(path):
             problems.append(f"{path}:{ln}: compiler-generated AGPR use in {kernel}: {code}")
         if code.startswith("v_accvgpr_write"):
             problems.append(f"{path}:{ln}: compiler-generated v_accvgpr_write in {kernel}: {code}")
+    # store-data race: [x3/x4 store] directly followed by a VALU write of data register 2 or 3
+    def regs(tok):
+        m = re.match(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return list(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.match(r"v(\d+)$", tok)
+        return [int(m.group(1))] if m else []
+    kernel, prev = None, None
+    for ln, line in enumerate(txt, 1):
+        m = re.match(r"^(_ZN\S*gemm_(?:[nt][nt]a|f8a)_kernel\S*):", line)
+        if m:
+            kernel, prev = m.group(1), None
+            continue
+        if line.startswith(".Lfunc_end"):
+            kernel = None
+        s = line.strip()
+        if kernel is None or not s or s[0] in ";." or s.endswith(":"):
+            continue
+        code = s.split(";")[0].strip()
+        if prev and code.startswith("v_") and not code.startswith("v_cmp"):
+            dst = regs(code.split()[1].rstrip(","))
+            if any(d in prev[1][2:] for d in dst):
+                problems.append(f"{path}:{ln}: {kernel}: `{code}` overwrites the tail of the data of `{prev[0]}` one slot after it")
+        prev = None
+        if re.match(r"(buffer|global|flat)_store_dwordx[34]", code):
+            prev = (code, regs(code.split()[1].rstrip(",")))
     # metadata
     meta = "\n".join(txt)
-    for m in re.finditer(r"\.name:\s+(\S*gemm_[nt][nt]a_kernel\S*)\n(.*?)\.wavefront_size", meta, re.S):
+    for m in re.finditer(r"\.name:\s+(\S*gemm_(?:[nt][nt]a|f8a)_kernel\S*)\n(.*?)\.wavefront_size", meta, re.S):
         name, body = m.group(1), m.group(2)
         for key in ("private_segment_fixed_size", "vgpr_spill_count"):
             v = re.search(rf"\.{key}:\s+(\d+)", body)
