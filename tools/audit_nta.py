@@ -18,6 +18,37 @@ import re
 import sys
 
 
+def store_data_races(path, txt, label=r"^(\w[\w.$]*):"):
+    """[12- / 16-byte store] directly followed by a VALU write (inline asm included) of its third or fourth data register, in
+    every function whose label matches `label` (default: every function of the file)."""
+    def regs(tok):
+        m = re.match(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return list(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.match(r"v(\d+)$", tok)
+        return [int(m.group(1))] if m else []
+    problems, kernel, prev = [], None, None
+    for ln, line in enumerate(txt, 1):
+        m = re.match(label, line)
+        if m:
+            kernel, prev = m.group(1), None
+            continue
+        if line.startswith(".Lfunc_end"):
+            kernel = None
+        s = line.strip()
+        if kernel is None or not s or s[0] in ";." or s.endswith(":"):
+            continue
+        code = s.split(";")[0].strip()
+        if prev and code.startswith("v_") and not code.startswith("v_cmp"):
+            dst = regs(code.split()[1].rstrip(","))
+            if any(d in prev[1][2:] for d in dst):
+                problems.append(f"{path}:{ln}: {kernel}: `{code}` overwrites the tail of the data of `{prev[0]}` one slot after it")
+        prev = None
+        if re.match(r"(buffer|global|flat)_store_dwordx[34]", code):
+            prev = (code, regs(code.split()[1].rstrip(",")))
+    return problems
+
+
 def audit(path):
     txt = open(path).read().splitlines()
     problems = []
@@ -49,32 +80,7 @@ def audit(path):
             problems.append(f"{path}:{ln}: compiler-generated AGPR use in {kernel}: {code}")
         if code.startswith("v_accvgpr_write"):
             problems.append(f"{path}:{ln}: compiler-generated v_accvgpr_write in {kernel}: {code}")
-    # store-data race: [x3/x4 store] directly followed by a VALU write of data register 2 or 3
-    def regs(tok):
-        m = re.match(r"v\[(\d+):(\d+)\]", tok)
-        if m:
-            return list(range(int(m.group(1)), int(m.group(2)) + 1))
-        m = re.match(r"v(\d+)$", tok)
-        return [int(m.group(1))] if m else []
-    kernel, prev = None, None
-    for ln, line in enumerate(txt, 1):
-        m = re.match(r"^(_ZN\S*gemm_(?:[nt][nt]a|f8a)_kernel\S*):", line)
-        if m:
-            kernel, prev = m.group(1), None
-            continue
-        if line.startswith(".Lfunc_end"):
-            kernel = None
-        s = line.strip()
-        if kernel is None or not s or s[0] in ";." or s.endswith(":"):
-            continue
-        code = s.split(";")[0].strip()
-        if prev and code.startswith("v_") and not code.startswith("v_cmp"):
-            dst = regs(code.split()[1].rstrip(","))
-            if any(d in prev[1][2:] for d in dst):
-                problems.append(f"{path}:{ln}: {kernel}: `{code}` overwrites the tail of the data of `{prev[0]}` one slot after it")
-        prev = None
-        if re.match(r"(buffer|global|flat)_store_dwordx[34]", code):
-            prev = (code, regs(code.split()[1].rstrip(",")))
+    problems += store_data_races(path, txt, r"^(_ZN\S*gemm_(?:[nt][nt]a|f8a)_kernel\S*):")
     # metadata
     meta = "\n".join(txt)
     for m in re.finditer(r"\.name:\s+(\S*gemm_(?:[nt][nt]a|f8a)_kernel\S*)\n(.*?)\.wavefront_size", meta, re.S):
