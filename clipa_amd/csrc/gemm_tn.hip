@@ -391,14 +391,17 @@ int ensure_tn_attrs(int dev) {
 }
 
 // Work order.  Slice-per-XCD (an XCD's workgroups all read the same M rows: fabric reads drop from ~2.2x to ~1.2x the
-// operand bytes) is +3..7 % on the image-tower shapes and -6 % on the text tower's narrow-P / wide-Q product, which
-// keeps the tile-per-XCD order (tools/tn_ab.py, profiles/r02_tn_ab.jsonl).  Experiment flags: 4096 forces the slice
-// order, 8192 the tile order.
+// operand bytes) is +1..10 % on the square and tall products and -4..-8 % on the narrow-P / wide-Q one (the c_proj weight
+// gradient: 1024 x 4096, 1280 x 5120, the text tower's 768 x 3072), which keeps the tile-per-XCD order with its fewer,
+// longer slices (round 2 with gemm_tn2/3: tools/tn_ab.py, profiles/r02_tn_ab.jsonl; round 3 with gemm_tna at the production
+// row counts: tools/probes/gemm_tn_order_sweep.hip, profiles/r03_gemm_tn_work_order_sweep.jsonl).  Experiment flags: 4096
+// forces the slice order, 8192 the tile order.
 bool tn_per_xcd(long M, long R, long C) {
   const int abl = g_abl.load(std::memory_order_relaxed);
   if (abl & 4096) return true;
   if (abl & 8192) return false;
-  return !(C >= 3 * R && M < 500000);
+  (void)M;
+  return !(C >= 3 * R);
 }
 
 long tn_slices(long M, long R, long C, int num_cu, bool per_xcd) {
