@@ -13,7 +13,8 @@ MI355X mapping.
   compute stream; the loss picks the result up (`self._pending`, matched by tensor IDENTITY) and only the text gather
   is exposed.  (The reference gathers both serially after both towers, loss.py:73-76.)  All of that state lives on the
   ClipLoss instance; a forward whose features never reach the loss unchanged (accum_freq > 1 concatenates them,
-  train.py:242-247) costs one unused gather, after which the instance stops gathering early.
+  train.py:242-247; the first iteration of DistributedDataParallel(static_graph=True) clones its outputs) costs one unused
+  gather; after three consecutive ones the instance stops gathering early.
 * Backward of the differentiable gather = ONE reduce-scatter(SUM) of the fused [W*B, 2E] fp32 gradient - the
   semantics of torch.distributed.nn.all_gather's backward used by the reference.
 * Similarity GEMM and cross-entropy are ONE kernel pair (`ops.simce`, csrc/simce.hip): the GEMM epilogue reduces each
@@ -178,7 +179,21 @@ class ClipLoss(nn.Module):
         self.use_horovod = use_horovod
         self.group = group
         self._pending = None        # (weakref(features), version, local bf16, gathered bf16, side-stream event)
-        self._early_ok = True       # cleared when an early gather went unused (features re-packed before the loss)
+        self._early_ok = True       # cleared when EARLY_MISS_LIMIT consecutive early gathers went unused
+        self._early_misses = 0      # consecutive early gathers whose tensor never reached the loss unchanged
+        self.early_hits = 0         # forwards that consumed an early gather (diagnostics / tests)
+
+    # An early gather goes unused when the loss does not see the very tensor the model returned: accum_freq > 1 (the loss
+    # sees torch.cat of cached features, train.py:242-247) misses on EVERY step, DistributedDataParallel(static_graph=True)
+    # only on its first iteration (its _DDPSink clones the outputs once).  One miss must therefore not switch the overlap
+    # off for good: it is switched off after this many CONSECUTIVE misses, and a hit re-arms the count.  Every rank runs
+    # the same forwards, so every rank takes the same decision at the same step (early_gather is a collective).
+    EARLY_MISS_LIMIT = 3
+
+    def _early_miss(self):
+        self._early_misses += 1
+        if self._early_misses >= self.EARLY_MISS_LIMIT:
+            self._early_ok = False
 
     def bind(self, model):
         """Opt in to the overlapped image-feature gather: `model` (a clipa_amd.CLIP, possibly inside DDP) will call
@@ -192,9 +207,11 @@ class ClipLoss(nn.Module):
         the text tower.  No-op for a single rank or once an early gather has gone unused."""
         if self.world_size <= 1 or not self._early_ok or not dist.is_available() or not dist.is_initialized():
             return
-        if self._pending is not None:          # the previous forward never reached the loss with its own tensor
-            self._pending, self._early_ok = None, False
-            return
+        if self._pending is not None:          # the previous forward never reached the loss at all (e.g. a no-loss forward)
+            self._pending = None
+            self._early_miss()
+            if not self._early_ok:
+                return
         local = ops.to_bf16(features.detach())
         gathered, ev = _all_gather_bf16(local, self.world_size, self.group)
         self._pending = (weakref.ref(features), features._version, local, gathered, ev)
@@ -204,8 +221,10 @@ class ClipLoss(nn.Module):
         if ent is None:
             return None
         if ent[0]() is features and ent[1] == features._version:
+            self._early_misses = 0
+            self.early_hits += 1
             return ent[2:]
-        self._early_ok = False                 # e.g. accum_freq > 1: the loss sees torch.cat(...) of cached features
+        self._early_miss()                     # e.g. accum_freq > 1: the loss sees torch.cat(...) of cached features
         return None
 
     def forward(self, image_features, text_features, logit_scale, output_dict=False):

@@ -44,13 +44,17 @@ def _worker(rank, world, port, q):
     B = g.images_u8.shape[0] // world
     img, txt = g.images_u8[rank * B:(rank + 1) * B], g.texts[rank * B:(rank + 1) * B]
     loss_fn = clipa_amd.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True, rank=rank, world_size=world).bind(ddp)
-    losses = []
-    for _ in range(2):
+    losses, hits = [], []
+    for _ in range(4):
         ddp.zero_grad(set_to_none=True)
         out = ddp(img, txt)
         loss = loss_fn(**out, output_dict=True)["contrastive_loss"]
         loss.backward()
         losses.append(float(loss.detach()))
+        hits.append(loss_fn.early_hits)
+    # DDP(static_graph=True) clones the outputs on its first iteration (one unused early gather); from the second
+    # iteration on the overlapped image-feature gather must really be the one the loss consumes
+    assert loss_fn._early_ok and hits[-1] - hits[0] == 3, hits
     grads = {n: p.grad.detach().float().numpy() for n, p in m.named_parameters() if p.grad is not None}
     q.put((rank, losses, grads))
     dist.barrier()
@@ -88,7 +92,7 @@ def test_two_rank_ddp_step_equals_global_batch_step():
             mod.ops = real_ops
     mean_local = 0.5 * (got[0][0][0] + got[1][0][0])
     assert abs(mean_local - float(loss)) <= 2e-3 * abs(float(loss)), (mean_local, float(loss))
-    assert abs(got[0][0][0] - got[0][0][1]) < 1e-6
+    assert max(abs(got[0][0][0] - l) for l in got[0][0][1:]) < 1e-6
     assert set(got[0][1]) == set(ref)
     for n, gref in ref.items():
         a, b = got[0][1][n], got[1][1][n]
