@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libclipa_hip.so")
 SOURCES = ["gemm_nt.hip", "gemm_nta.hip", "gemm_tn.hip", "gemm_tna.hip", "gemm_f8.hip", "gemm_f8a.hip", "quant.hip", "simce.hip", "layernorm.hip", "attention.hip", "misc.hip", "augment.hip", "runtime.hip"]
-AUDITED = {"gemm_nta.hip": "audit_nta.py", "gemm_tna.hip": "audit_nta.py", "gemm_f8a.hip": "audit_nta.py"}          # source -> tools/<script> run on its device assembly
+AUDITED = ("gemm_nta.hip", "gemm_tna.hip", "gemm_f8a.hip")          # sources whose device assembly clipa_amd/isa_audit.py checks
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", CSRC, "-I", os.path.join(ROOT, "include"),
          "-Wno-unused-result", "-ffp-contract=fast"]
@@ -57,9 +57,12 @@ def build(force=False, verbose=False):
             # hand-counted waits / literally named registers are only valid for the code hipcc actually emitted: the static
             # audits are part of the build, not only of the test-suite
             asm = os.path.join(objdir, src.replace(".hip", "-hip-amdgcn-amd-amdhsa-gfx950.s"))
-            a = subprocess.run([sys.executable, os.path.join(ROOT, "tools", AUDITED[src]), asm], capture_output=True, text=True)
+            if not os.path.isfile(asm):
+                raise RuntimeError(f"ISA audit of {src}: device assembly {asm} not found - this hipcc names its -save-temps "
+                                   f"files differently (present: {sorted(f for f in os.listdir(objdir) if f.endswith('.s'))})")
+            a = subprocess.run([sys.executable, os.path.join(HERE, "isa_audit.py"), asm], capture_output=True, text=True)
             if a.returncode != 0:
-                raise RuntimeError(f"ISA audit of {src} failed ({AUDITED[src]}):\n{a.stdout[-3000:]}\n{a.stderr[-2000:]}")
+                raise RuntimeError(f"ISA audit of {src} failed (clipa_amd/isa_audit.py):\n{a.stdout[-3000:]}\n{a.stderr[-2000:]}")
         return obj
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:

@@ -20,7 +20,7 @@ struct NTArgs {
   long lda, ldb, ldc, ldaux;   // element strides
   float alpha;
   int epi, act;
-  int abl;   // experiment flags (clipa_debug_set): 1 no global stores, 2 no epilogue, 8 row-major tile order
+  int abl;   // experiment flags (clipa_internal_debug_set): 1 no global stores, 2 no epilogue, 8 row-major tile order
   int gm;    // A panels per tile group (nt_group_size)
 };
 
@@ -42,7 +42,7 @@ struct TNArgs {
   int slice_rows;   // multiple of 64
   float* colsum;    // optional [S][R] partial column sums of P (the bias gradient rides the weight-gradient GEMM)
   int nslices;      // > 0: 1-D grid, XCD x owns the M slices x, x+8, ... (all tiles of a slice share one L2)
-  int abl;          // experiment flags (clipa_debug_set), gemm_tna only
+  int abl;          // experiment flags (clipa_internal_debug_set), gemm_tna only
 };
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -318,9 +318,9 @@ __device__ __forceinline__ void lds_read4_f1(float (&v)[4], const char* base) { 
 // from the device the call runs on.  No process-wide mutable state besides the experiment knobs (atomics).
 int gemm_num_cu(int dev);                 // multiProcessorCount of `dev`, cached
 int current_device(int* dev);             // hipGetDevice with error reporting
-extern std::atomic<int> g_nt_variant;     // clipa_debug_set: gemm_nt kernel selection (0 = per-shape default)
-extern std::atomic<int> g_abl;            // clipa_debug_set: experiment flags
-extern std::atomic<int> g_last_gemm;      // clipa_debug_last_gemm: 1 gemm_nt2, 2 gemm_nta, 3 gemm_tn2, 4 gemm_tn3, 5 gemm_tna
+extern std::atomic<int> g_nt_variant;     // clipa_internal_debug_set: gemm_nt kernel selection (0 = per-shape default)
+extern std::atomic<int> g_abl;            // clipa_internal_debug_set: experiment flags
+extern std::atomic<int> g_last_gemm;      // clipa_internal_last_gemm: 1 gemm_nt2, 2 gemm_nta, 3 gemm_tn2, 4 gemm_tn3, 5 gemm_tna
 
 constexpr int MAX_DEVICES = 64;
 

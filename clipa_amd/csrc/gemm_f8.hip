@@ -248,7 +248,7 @@ extern "C" int clipa_gemm_nt_f8(const void* A8, const void* B8, const float* sca
   a.gm = nt_group_size((N + BN - 1) / BN, 256L * K);
   hipStream_t st = (hipStream_t)stream;
   // whole-tile shapes with e4m3 weights (every block GEMM of the BASELINE configurations) run on the four-wave kernel with the
-  // hand-scheduled main loop (gemm_f8a.hip); bit-identical outputs.  clipa_debug_set(1, .) keeps them on this file's kernel.
+  // hand-scheduled main loop (gemm_f8a.hip); bit-identical outputs.  clipa_internal_debug_set(1, .) keeps them on this file's kernel.
   if (g_nt_variant.load(std::memory_order_relaxed) != 1 && !(a.abl & 13) && f8a_eligible(M, N, K, fmt_b)) {
     F8AArgs b;
     b.A = a.A; b.B = a.B; b.C = a.C; b.C2 = a.C2; b.bias = a.bias; b.aux = a.aux; b.sa = a.sa; b.sb = a.sb;

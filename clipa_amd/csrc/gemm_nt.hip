@@ -14,8 +14,10 @@
 // The round-1 generations (one tile per workgroup, loader/storer wave roles, ping-pong main loops) are in the git
 // history only; the round-2 experiments (direct MFMA-fragment epilogue, two workgroups per CU, five-slot K-32 ring,
 // deferred stores: none beat this kernel by more than its run-to-run noise except on one epilogue) are in
-// experiments/gemm_nt_round2.hip, outside libclipa_hip.so; measurements in profiles/r02_gemm_epilogue_experiments.md.
+// tools/experiments/gemm_nt_round2.hip, outside the package and libclipa_hip.so; measurements in profiles/r02_gemm_epilogue_experiments.md.
 #include "gemm_common.h"
+#include "internal_hooks.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace clipa_gemm {
@@ -330,13 +332,20 @@ int gemm_num_cu(int dev) {
 
 using namespace clipa_gemm;
 
-extern "C" int clipa_debug_set(int gemm_nt_variant, int ablation_flags) {
+extern "C" int clipa_internal_debug_set(int gemm_nt_variant, int ablation_flags) {
+  if (gemm_nt_variant != 0 || ablation_flags != 0) {      // a reset is always allowed; anything else only in a harness process
+    const char* on = getenv("CLIPA_DEBUG_HOOKS");
+    if (!on || on[0] != '1') {
+      clipa_set_error("clipa_internal_debug_set: kernel-experiment hooks are disabled (set CLIPA_DEBUG_HOOKS=1 in a test / A-B harness process)");
+      return CLIPA_ERR_ARG;
+    }
+  }
   g_nt_variant.store(gemm_nt_variant, std::memory_order_relaxed);
   g_abl.store(ablation_flags, std::memory_order_relaxed);
   return CLIPA_OK;
 }
 
-extern "C" int clipa_debug_last_gemm(void) { return g_last_gemm.load(std::memory_order_relaxed); }
+extern "C" int clipa_internal_last_gemm(void) { return g_last_gemm.load(std::memory_order_relaxed); }
 
 extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, const float* bias,
                              const void* aux, int64_t M, int64_t N, int64_t K, int64_t lda,
@@ -359,11 +368,11 @@ extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, co
   a.M = (int)M; a.N = (int)N; a.K = (int)K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
   a.alpha = alpha; a.epi = epi; a.act = act; a.abl = g_abl.load(std::memory_order_relaxed);
   a.gm = nt_group_size((N + BN - 1) / BN, 256L * K * 2);
-  if ((a.abl >> 20) & 63) a.gm = (a.abl >> 20) & 63;       // experiment: tile-group size override (clipa_debug_set flags bits 20..25)
+  if ((a.abl >> 20) & 63) a.gm = (a.abl >> 20) & 63;       // experiment: tile-group size override (clipa_internal_debug_set flags bits 20..25)
   hipStream_t st = (hipStream_t)stream;
   // whole-tile bf16 shapes (every block GEMM of the BASELINE configurations at batch multiples of 256) run on the four-wave
-  // kernel with the hand-scheduled main loop (gemm_nta.hip); bit-identical outputs.  clipa_debug_set(1, .) keeps them on
-  // gemm_nt2, clipa_debug_set(2 + s, .) selects generated schedule s (A/B harnesses)
+  // kernel with the hand-scheduled main loop (gemm_nta.hip); bit-identical outputs.  clipa_internal_debug_set(1, .) keeps them on
+  // gemm_nt2, clipa_internal_debug_set(2 + s, .) selects generated schedule s (A/B harnesses)
   const int variant = g_nt_variant.load(std::memory_order_relaxed);
   g_last_gemm.store(1, std::memory_order_relaxed);
   if (variant != 1 && !(a.abl & 13 & 0xfffff) && nta_eligible(a, out_f32))

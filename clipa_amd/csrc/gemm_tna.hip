@@ -81,7 +81,7 @@ __global__ __launch_bounds__(TNA_THREADS) void gemm_tna_kernel(TNArgs p) {
   const u32x4 curP = make_srd(p.P + ((size_t)mbeg * p.ldp + r0) * 2, (unsigned)min((long)0xffffff00L, (long)rows * p.ldp * 2));
   const u32x4 curQ = make_srd(p.Q + ((size_t)mbeg * p.ldq + c0) * 2, (unsigned)min((long)0xffffff00L, (long)rows * p.ldq * 2));
   const u32x4 nul = make_srd(p.P, 0u);
-  // ablations (clipa_debug_set flags; wrong results): 65536 = operands never fetched (the LDS-DMA write zeros: LDS traffic
+  // ablations (clipa_internal_debug_set flags; wrong results): 65536 = operands never fetched (the LDS-DMA write zeros: LDS traffic
   // without L2 traffic), 131072 = every K step re-reads the slice's first 64 rows (operand bytes stay L2-resident)
   const int abl = p.abl;
   const u32x4 useP = (abl & 65536) ? nul : curP, useQ = (abl & 65536) ? nul : curQ;

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Static audit of the gemm_nta kernels' ISA (run by clipa_amd.build after compiling gemm_nta.hip with -save-temps).
+"""Static audit of the generated-loop GEMM kernels' ISA (gemm_nta / gemm_tna / gemm_f8a), run by clipa_amd.build on the device
+assembly hipcc emitted (-save-temps) - part of the package so that a copy of clipa_amd without tools/ still builds.
 
 The accumulators of gemm_nta_kernel live in a[0:255] between the tile's inline-asm statement and the v_accvgpr_read
 statements of the epilogue - something hipcc does not know.  That is safe exactly as long as the compiler itself never
@@ -12,8 +13,14 @@ touches an accumulation register and never spills (cdna_hip_programming.md 5.7 i
     data: on gfx950 that write wins the race against the store's operand read (observed in gemm_f8a: lanes 12-15 of every 16
     stored the next chunk's values); the first two registers, or one instruction of distance, are safe (every bit-exact test
     of gemm_nta exercises them).
-Usage: python tools/audit_nta.py <file.s>   -> exit code 0 / 1, findings on stdout.
+  * store counts: the tile statement waits with `s_waitcnt vmcnt(16 + S)`, S = the 16-byte stores the epilogue in front of it
+    left in flight (32 per wave and output; NTA_TILE / F8A_TILE macro argument).  If hipcc ever emitted FEWER stores than S
+    (merged / dropped), the wait would let the tile's first operands be read before they landed; MORE (split stores) is safe
+    but slow.  Every copy of the epilogue (one per activation) is bracketed by `; CLIPA_EPI_BEGIN k` / `; CLIPA_EPI_END k`
+    comment markers and must hold exactly S `buffer_store_dwordx4` in one straight-line block.
+Usage: python -m clipa_amd.isa_audit <file.s>   -> exit code 0 / 1, findings on stdout.
 """
+import os
 import re
 import sys
 
@@ -49,6 +56,59 @@ def store_data_races(path, txt, label=r"^(\w[\w.$]*):"):
     return problems
 
 
+def epilogue_store_counts(path, txt):
+    """gemm_nta_kernel<EPI, PRE, .> / gemm_f8a_kernel<EPI, PRE, .>: every epilogue copy (between its `; CLIPA_EPI_BEGIN k` and
+    `; CLIPA_EPI_END k` markers, one straight-line block) holds exactly the 16-byte stores the tile statement's wait assumes:
+    32 per output.  hipcc's structurizer makes a path walk over the basic blocks useless (correlated flow predicates), and
+    totals per kernel say nothing (it tail-merges identical stores of the three activation copies) - hence the markers."""
+    problems, kernel, open_k, count, copies = [], None, None, 0, 0
+
+    def want(kname):
+        m = re.search(r"gemm_(?:nta|f8a)_kernelILi(\d+)ELb([01])E", kname)
+        return 32 * (2 if m and m.group(2) == "1" else 1)
+
+    def close_kernel():
+        if kernel is not None and copies == 0:
+            problems.append(f"{path}: {kernel}: no CLIPA_EPI_BEGIN / END markers found (epilogue store count unchecked)")
+        if kernel is not None and open_k is not None:
+            problems.append(f"{path}: {kernel}: CLIPA_EPI_BEGIN {open_k} without its END")
+
+    for ln, line in enumerate(txt, 1):
+        m = re.match(r"^(_ZN\S*gemm_(?:nta|f8a)_kernel\S*):", line)
+        if m:
+            close_kernel()
+            kernel, open_k, count, copies = m.group(1), None, 0, 0
+            continue
+        if line.startswith(".Lfunc_end"):
+            close_kernel()
+            kernel = None
+        if kernel is None:
+            continue
+        s = line.strip()
+        m = re.match(r";\s*CLIPA_EPI_(BEGIN|END)\s+(\d+)", s)
+        if m and m.group(1) == "BEGIN":
+            if open_k is not None:
+                problems.append(f"{path}:{ln}: {kernel}: nested CLIPA_EPI_BEGIN")
+            open_k, count = m.group(2), 0
+        elif m:
+            if open_k != m.group(2):
+                problems.append(f"{path}:{ln}: {kernel}: CLIPA_EPI_END {m.group(2)} does not close BEGIN {open_k}")
+            elif count != want(kernel):
+                problems.append(f"{path}:{ln}: {kernel}: epilogue copy {open_k} issues {count} buffer_store_dwordx4, the tile "
+                                f"statement's vmcnt assumes {want(kernel)}")
+            open_k, copies = None, copies + 1
+        elif open_k is not None:
+            code = s.split(";")[0].strip()
+            if re.match(r"buffer_store_dwordx4\b", code):
+                count += 1
+            elif re.match(r"(buffer|global|flat)_store_", code):
+                problems.append(f"{path}:{ln}: {kernel}: store of another width inside the epilogue: `{code}`")
+            elif re.match(r"\.LBB\w+:", s) or code.startswith("s_cbranch") or code.startswith("s_branch") or code.startswith("s_setpc"):
+                problems.append(f"{path}:{ln}: {kernel}: control flow inside an epilogue copy: `{s}`")
+    close_kernel()
+    return problems
+
+
 def audit(path):
     txt = open(path).read().splitlines()
     problems = []
@@ -81,6 +141,7 @@ def audit(path):
         if code.startswith("v_accvgpr_write"):
             problems.append(f"{path}:{ln}: compiler-generated v_accvgpr_write in {kernel}: {code}")
     problems += store_data_races(path, txt, r"^(_ZN\S*gemm_(?:[nt][nt]a|f8a)_kernel\S*):")
+    problems += epilogue_store_counts(path, txt)
     # metadata
     meta = "\n".join(txt)
     for m in re.finditer(r"\.name:\s+(\S*gemm_(?:[nt][nt]a|f8a)_kernel\S*)\n(.*?)\.wavefront_size", meta, re.S):
@@ -96,8 +157,11 @@ def audit(path):
 
 
 if __name__ == "__main__":
+    if not os.path.isfile(sys.argv[1]):
+        print(f"isa_audit: assembly file {sys.argv[1]} not found (hipcc -save-temps naming changed?)")
+        sys.exit(2)
     bad = audit(sys.argv[1])
     for b in bad[:40]:
         print(b)
-    print(f"audit_nta: {len(bad)} finding(s)")
+    print(f"isa_audit: {len(bad)} finding(s)")
     sys.exit(1 if bad else 0)

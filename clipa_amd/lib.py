@@ -18,8 +18,6 @@ _P, _I64, _I32, _F = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_float
 SIGNATURES = {
     "clipa_last_error": (_c.c_char_p, []),
     "clipa_version": (_I32, []),
-    "clipa_debug_set": (_I32, [_I32, _I32]),
-    "clipa_debug_last_gemm": (_I32, []),
     "clipa_gemm_nt": (_I32, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I32, _I32, _I32, _P]),
     "clipa_gemm_tn_workspace": (_I64, [_I64, _I64, _I64, _c.POINTER(_I64)]),
     "clipa_gemm_tn": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I32, _P, _I64, _P]),
@@ -86,6 +84,27 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def debug_set(gemm_nt_variant=0, flags=0):
+    """Tests / A-B harnesses only (csrc/internal_hooks.h, not part of the C ABI): force a GEMM kernel family or an ablation
+    for this process.  Enables the hook through the environment (CLIPA_DEBUG_HOOKS=1); call with no arguments to reset."""
+    lib = load()
+    fn = lib.clipa_internal_debug_set
+    fn.restype, fn.argtypes = _I32, [_I32, _I32]
+    if gemm_nt_variant or flags:
+        os.environ["CLIPA_DEBUG_HOOKS"] = "1"
+    rc = fn(int(gemm_nt_variant), int(flags))
+    if rc != 0:
+        raise RuntimeError(f"clipa_internal_debug_set failed (rc={rc}): {last_error()}")
+
+
+def last_gemm():
+    """Kernel family of this process's last GEMM launch (csrc/internal_hooks.h): 1 gemm_nt2, 2 gemm_nta, 3 gemm_tn2,
+    4 gemm_tn3, 5 gemm_tna, 6 gemm_f8a, 7 gemm_nt_f8_kernel."""
+    fn = load().clipa_internal_last_gemm
+    fn.restype, fn.argtypes = _I32, []
+    return int(fn())
 
 
 def last_error():

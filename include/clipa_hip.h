@@ -40,16 +40,6 @@ extern "C" {
 
 const char* clipa_last_error(void);
 int clipa_version(void);
-/* kernel-experiment hook (tools/tn_ab.py, tests: in-process A/B; two relaxed atomics).  gemm_nt_variant is reserved (the
- * round-2 gemm_nt experiments live outside the library); flags: gemm_nt 2 = main loop only, 8 = row-major tile order;
- * gemm_tn 1024 / 2048 force the 16x16x32 / ping-pong kernel, 4096 / 8192 force the slice-per-XCD / tile-per-XCD work
- * order, 16384 keeps whole-tile shapes off gemm_tna, 32768 selects its schedule 1; gemm_nt_variant 1 keeps whole-tile shapes
- * on gemm_nt2 (and whole-tile fp8 shapes on gemm_nt_f8_kernel), 2 + s selects schedule s of gemm_nta; gemm_nta / gemm_f8a 64 = epilogue
- * stores dropped by the bounds check (gemm_nta), 128 = every tile stores to tile 0.  Production callers never touch it. */
-int clipa_debug_set(int gemm_nt_variant, int ablation_flags);
-/* Which GEMM kernel family the calling process launched last (A/B harnesses and tests check that a shape really ran where
- * they think it did): 0 none, 1 gemm_nt2, 2 gemm_nta, 3 gemm_tn2, 4 gemm_tn3, 5 gemm_tna, 6 gemm_f8a, 7 gemm_nt_f8_kernel. */
-int clipa_debug_last_gemm(void);
 
 /* C[M,N] = epi(alpha * A[M,K] . B[N,K]^T + bias[N]); A,B bf16; C bf16 (or f32 when out_f32, epi NONE).
  * Replaces nn.Linear / packed in-proj / out-proj / conv1-as-GEMM / `@ proj` forward and, with B = W^T,

@@ -130,20 +130,16 @@ def test_gemm_nt_f8_epilogues(act):
 
 
 def _debug_set(variant, abl):
-    import ctypes
     from clipa_amd import lib
-    h = lib.load()
-    h.clipa_debug_set.argtypes = [ctypes.c_int, ctypes.c_int]
-    h.clipa_debug_last_gemm.restype = ctypes.c_int
-    assert h.clipa_debug_set(variant, abl) == 0
-    return h
+    lib.debug_set(variant, abl)          # csrc/internal_hooks.h: not part of the C ABI, enabled per process through the environment
+    return lib
 
 
 @pytest.mark.parametrize("fmt_a", [0, 1])
 @pytest.mark.parametrize("M,N,K", [(512, 256, 768), (1024, 768, 512), (768, 512, 1280)])
 def test_gemm_f8a_matches_gemm_nt_f8(M, N, K, fmt_a):
     """Whole-tile shapes run on gemm_f8a (four waves, generated main loop, gemm_f8a.hip); every epilogue against the oracle and BIT
-    FOR BIT against gemm_nt_f8_kernel (clipa_debug_set(1, .) keeps that kernel), several tiles per workgroup, both A formats."""
+    FOR BIT against gemm_nt_f8_kernel (lib.debug_set(1, .) keeps that kernel), several tiles per workgroup, both A formats."""
     o = ops()
     qa, sa, qb, sb, lin = _f8_operands(M, N, K, fmt_a, 0, seed=31 + fmt_a)
     bias, aux = rnd(N, seed=8, dtype=f32), rnd(M, N, seed=9)
@@ -158,10 +154,10 @@ def test_gemm_f8a_matches_gemm_nt_f8(M, N, K, fmt_a):
     try:
         h = _debug_set(1, 0)
         old = run()
-        assert h.clipa_debug_last_gemm() == 7
+        assert h.last_gemm() == 7
         _debug_set(0, 0)
         new = run()
-        assert h.clipa_debug_last_gemm() == 6, "the whole-tile shape did not reach gemm_f8a"
+        assert h.last_gemm() == 6, "the whole-tile shape did not reach gemm_f8a"
         again = run()
     finally:
         _debug_set(0, 0)

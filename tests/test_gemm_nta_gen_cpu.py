@@ -1,7 +1,7 @@
 """gemm_nta (clipa_amd/csrc/gemm_nta.hip): the main loop is generated text and the accumulators live in registers hipcc does
 not know about.  Without a GPU this checks that (1) the committed gemm_nta_asm.inc IS what tools/gen_gemm_nta.py generates,
 (2) every schedule keeps the pipeline's ordering rules (slot freed before it is re-filled, publish wait after the step's last
-LDS-DMA, fragment registers not re-loaded before their last use), and (3) the cross-compiled ISA passes tools/audit_nta.py:
+LDS-DMA, fragment registers not re-loaded before their last use), and (3) the cross-compiled ISA passes clipa_amd/isa_audit.py:
 no scratch, no compiler-generated access to an accumulation register, 512 registers per wave."""
 import os
 import re
@@ -63,7 +63,7 @@ def test_isa_audit(tmp_path):
            os.path.join(ROOT, "clipa_amd", "csrc", "gemm_nta.hip")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    a = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_nta.py"), str(asm)], capture_output=True, text=True)
+    a = subprocess.run([sys.executable, os.path.join(ROOT, "clipa_amd", "isa_audit.py"), str(asm)], capture_output=True, text=True)
     assert a.returncode == 0, a.stdout[-3000:]
     assert len(re.findall(r"\.name:\s+\S*gemm_nta_kernel", asm.read_text())) == 15
 
@@ -96,7 +96,7 @@ def test_tn_isa_audit(tmp_path):
            os.path.join(ROOT, "clipa_amd", "csrc", "gemm_tna.hip")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    a = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_nta.py"), str(asm)], capture_output=True, text=True)
+    a = subprocess.run([sys.executable, os.path.join(ROOT, "clipa_amd", "isa_audit.py"), str(asm)], capture_output=True, text=True)
     assert a.returncode == 0, a.stdout[-3000:]
 
 
@@ -144,7 +144,7 @@ def test_f8a_isa_audit(tmp_path):
            os.path.join(ROOT, "clipa_amd", "csrc", "gemm_f8a.hip")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    a = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_nta.py"), str(asm)], capture_output=True, text=True)
+    a = subprocess.run([sys.executable, os.path.join(ROOT, "clipa_amd", "isa_audit.py"), str(asm)], capture_output=True, text=True)
     assert a.returncode == 0, a.stdout[-3000:]
     assert len(re.findall(r"\.name:\s+\S*gemm_f8a_kernel", asm.read_text())) == 10
 
@@ -152,8 +152,7 @@ def test_f8a_isa_audit(tmp_path):
 def test_audit_rejects_a_store_data_race(tmp_path):
     """The rule gemm_f8a's first hardware run paid for: a VALU write of the third / fourth data register in the slot right
     behind a 16-byte store."""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import audit_nta
+    from clipa_amd import isa_audit as audit_nta
     head = "_ZN10clipa_gemm12_GLOBAL__N_115gemm_f8a_kernelILi0ELb0ELi0EEEvNS_7F8AArgsE:\n"
     bad = head + "\tbuffer_store_dwordx4 v[6:9], v101, s[40:43], s96 offen\n\tv_pk_mul_f32 v[8:9], v[100:101], v[18:19]\n.Lfunc_end0:\n"
     ok = head + "\tbuffer_store_dwordx4 v[6:9], v101, s[40:43], s96 offen\n\ts_nop 0\n\tv_pk_mul_f32 v[8:9], v[100:101], v[18:19]\n.Lfunc_end0:\n"
@@ -161,4 +160,19 @@ def test_audit_rejects_a_store_data_race(tmp_path):
     for name, text, n in (("bad", bad, 1), ("ok", ok, 0), ("ok2", ok2, 0)):
         p = tmp_path / (name + ".s")
         p.write_text(text)
-        assert len(audit_nta.audit(str(p))) == n, name
+        assert len(audit_nta.store_data_races(str(p), text.splitlines())) == n, name
+
+
+def test_audit_counts_the_epilogue_stores(tmp_path):
+    """The tile statement waits with vmcnt(16 + S), S = the 16-byte stores the epilogue in front of it issued: a copy of the
+    epilogue with fewer (merged / dropped) stores would let operands be read before they landed.  Every copy is
+    bracketed by markers and counted; a missing marker pair is a finding as well."""
+    from clipa_amd import isa_audit
+    head = "_ZN10clipa_gemm12_GLOBAL__N_115gemm_nta_kernelILi1ELb1ELi4EEEvNS_6NTArgsE:\n"
+    st = "\tbuffer_store_dwordx4 v[6:9], v101, s[40:43], s96 offen\n\ts_nop 0\n"
+    def body(n):
+        return head + "\t;;#ASMSTART\n\t; CLIPA_EPI_BEGIN 0\n\t;;#ASMEND\n" + st * n + "\t;;#ASMSTART\n\t; CLIPA_EPI_END 0\n\t;;#ASMEND\n.Lfunc_end0:\n"
+    assert isa_audit.epilogue_store_counts("x", body(64).splitlines()) == []          # PRE: two outputs x 32
+    assert len(isa_audit.epilogue_store_counts("x", body(63).splitlines())) == 1
+    assert len(isa_audit.epilogue_store_counts("x", body(65).splitlines())) == 1
+    assert len(isa_audit.epilogue_store_counts("x", (head + st * 64 + ".Lfunc_end0:\n").splitlines())) == 1   # no markers

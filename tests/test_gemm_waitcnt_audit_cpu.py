@@ -40,11 +40,10 @@ def test_hand_counted_waits_hold_on_the_assembly(tmp_path, src, min_kernels):
 def test_no_store_data_race_in_any_kernel(tmp_path):
     """gfx950: a VALU write of the third / fourth data register of a 12- / 16-byte store in the slot right behind it overtakes the
     store's operand read (found on gemm_f8a's first hardware run; hipcc does not model it for stores with an SGPR offset).  Every
-    kernel file of the library is cross-compiled and scanned (tools/audit_nta.py: store_data_races)."""
+    kernel file of the library is cross-compiled and scanned (clipa_amd/isa_audit.py: store_data_races)."""
     from concurrent.futures import ThreadPoolExecutor
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
     sys.path.insert(0, ROOT)
-    import audit_nta
+    from clipa_amd import isa_audit as audit_nta
     from clipa_amd.build import SOURCES
 
     def one(src):

@@ -87,11 +87,53 @@ def test_gemm_nt_epilogues(act):
 
 
 def _debug_set(variant, abl):
-    import ctypes
     from clipa_amd import lib
-    h = lib.load()
-    h.clipa_debug_set.argtypes = [ctypes.c_int, ctypes.c_int]
-    assert h.clipa_debug_set(variant, abl) == 0
+    lib.debug_set(variant, abl)          # csrc/internal_hooks.h: not part of the C ABI, enabled per process through the environment
+
+
+def _last_gemm():
+    from clipa_amd import lib
+    return lib.last_gemm()
+
+
+NTA, NT2, TNA = 2, 1, 5                  # kernel families reported by lib.last_gemm()
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 768, 512), (2304, 512, 256), (512, 1024, 1152)])
+def test_gemm_nta_small_shapes_every_epilogue_bitwise_vs_nt2(M, N, K):
+    """The four-wave hand-scheduled kernel (gemm_nta.hip) on SMALL whole-tile shapes - several tiles per persistent workgroup
+    when there are fewer workgroups than tiles is exercised by the production-width tests; here 8-18 tiles, 4-18 K steps,
+    every epilogue, against fp64 AND bit for bit against gemm_nt2 (the round-1/2 kernel it replaced), and the dispatch itself:
+    a silent regression of whole-tile shapes to gemm_nt2 would otherwise pass every value test."""
+    o = ops()
+    a, b = rnd(M, K, seed=M + 1), rnd(N, K, seed=N + 2, scale=0.06)
+    bias, aux = rnd(N, seed=3, dtype=f32), rnd(M, N, seed=4)
+    A, B, BIAS, AUX = a.to(DEV), b.to(DEV), bias.to(DEV), aux.to(DEV)
+    lin = a.double() @ b.double().T * 0.5 + bias.double()
+
+    def run():
+        act, pre = o.gemm_nt(A, B, BIAS, alpha=0.5, epi=o.EPI_ACT, act=0, want_pre=True)
+        return (o.gemm_nt(A, B, BIAS, alpha=0.5), act, pre, o.gemm_nt(A, B, BIAS, alpha=0.5, epi=o.EPI_ACT, act=1),
+                o.gemm_nt(A, B, BIAS, alpha=0.5, epi=o.EPI_ACT, act=2), o.gemm_nt(A, B, None, alpha=0.5, epi=o.EPI_ADD, aux=AUX),
+                o.gemm_nt(A, B, BIAS, alpha=0.5, epi=o.EPI_DACT, act=0, aux=AUX))
+    names = ("bias", "gelu", "pre", "gelu_tanh", "quick_gelu", "residual", "gelu_bwd")
+    try:
+        _debug_set(1, 0)
+        old = run()
+        assert _last_gemm() == NT2
+        _debug_set(0, 0)
+        new = run()
+        assert _last_gemm() == NTA, "a whole-tile bf16 shape did not reach gemm_nta"
+        again = run()
+    finally:
+        _debug_set(0, 0)
+    check("bias", new[0], lin, 2 ** -7, 2e-3)
+    check("pre", new[2], lin, 2 ** -7, 2e-3)
+    check("gelu", new[1], ref_act(new[2].double().cpu(), 0), 2 ** -7, 2e-3)
+    check("residual", new[5], (a.double() @ b.double().T * 0.5).to(bf16).double() + aux.double(), 2 ** -7, 1.6e-2)
+    for name, x, y, z in zip(names, old, new, again):
+        assert torch.equal(x, y), f"{name}: gemm_nta differs from gemm_nt2"
+        assert torch.equal(y, z), f"{name}: second launch differs"
 
 
 def test_gemm_nt_ragged_shapes_every_epilogue():
@@ -154,6 +196,7 @@ def test_gemm_nt_production_width_values(N, K):
     v = lin.to(bf16).double()                                  # the engine rounds the GEMM result to bf16 before the epilogue
     auxr = aux[rows].double().cpu()
     out = o.gemm_nt(a, b, bias)
+    assert _last_gemm() == NTA, "the production MLP shape did not reach gemm_nta"
     check("bias", out[rows], lin, 2 ** -7, 2e-3)
     assert torch.isfinite(out.float()).all()
     del out
@@ -180,6 +223,7 @@ def test_gemm_tn_production_rows():
     p = (torch.randn(M, R, generator=g) * 0.05).to(bf16)
     q = (torch.randn(M, C, generator=g) * 0.05).to(bf16)
     w, cs = o.gemm_tn(p.to(DEV), q.to(DEV), f32, want_colsum=True)
+    assert _last_gemm() == TNA, "the production weight-gradient shape did not reach gemm_tna"
     ref = p.double().T @ q.double()
     check("weight gradient", w, ref, 1e-3, 5e-3)
     check("column sums", cs, p.double().sum(0), 1e-4, 5e-3)

@@ -11,7 +11,7 @@
 // steps of landing time for the A operand change nothing, so the A stream's HBM latency is not what the K step waits for either.
 // The mirrored ring (three B slots, two A slots: clipa_gemm_nt7, profiles/r02_gemm_b3a2_ring_ab.jsonl) is bit-identical too and within
 // -4...+3 %: neither operand's landing time alone is the constraint.
-// Self-contained: tools/build_variant.sh nt6 experiments/gemm_nt6_a3b2_ring.hip ; entry point clipa_gemm_nt6 (signature of
+// Self-contained: tools/build_variant.sh nt6 tools/experiments/gemm_nt6_a3b2_ring.hip ; entry point clipa_gemm_nt6 (signature of
 // clipa_gemm_nt, bf16 output, K > 64); tools/gemm_nt4_ab.py nt6 compares it with the production kernel.
 #include "../gemm_common.h"
 #include <mutex>

@@ -70,9 +70,9 @@ def main():
     import ctypes
     from clipa_amd import lib
     h = lib.load()
-    h.clipa_debug_set(0, 2)
+    lib.debug_set(0, 2)
     run(ML, 4096, 1024, "none", rounds, iters)
-    h.clipa_debug_set(0, 0)
+    lib.debug_set(0, 0)
     # LayerNorm with / without the fused fp8 output
     x = torch.randn(ML, 1024, device=DEV).to(bf16)
     g, b = torch.ones(1024, device=DEV), torch.zeros(1024, device=DEV)

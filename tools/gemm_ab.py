@@ -8,7 +8,6 @@ M, N, K = (int(x) for x in sys.argv[1:4])
 epi = sys.argv[4]
 variants = [tuple(int(v) for v in a.split(":")) for a in sys.argv[5:]]
 h = lib.load()
-h.clipa_debug_set.argtypes = [ctypes.c_int, ctypes.c_int]
 bf16 = torch.bfloat16
 torch.manual_seed(0)
 PAD = int(os.environ.get("PAD", "0"))      # extra elements in the leading dimension of a and w (channel-camping probe)
@@ -23,7 +22,7 @@ def run():
 times = {v: [] for v in variants}
 for rnd in range(7):
     for v in variants:
-        h.clipa_debug_set(v[0], v[1])
+        lib.debug_set(v[0], v[1])
         run(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -7,7 +7,6 @@ from clipa_amd import ops, lib
 
 var = int(sys.argv[1]); ref = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 h = lib.load()
-h.clipa_debug_set.argtypes = [ctypes.c_int, ctypes.c_int]
 bf16 = torch.bfloat16
 shapes = [(256, 256, 96), (512, 768, 128), (300, 264, 104), (1000, 520, 776), (4096, 1024, 1024), (777, 3072, 768),
           (2048, 256, 4096), (197 * 64, 4096, 1024), (65536, 1024, 96), (131, 8, 512)]
@@ -22,7 +21,7 @@ for (M, N, K) in shapes:
                      ("res", dict(bias=bias, epi=ops.EPI_ADD, aux=aux)), ("dact", dict(epi=ops.EPI_DACT, aux=aux))):
         outs = []
         for v in (ref, var, var):          # twice: catches ring state carried between launches
-            h.clipa_debug_set(v, 0)
+            lib.debug_set(v, 0)
             kw2 = dict(kw); b = kw2.pop("bias", None)
             o = ops.gemm_nt(a, w, b, **kw2)
             torch.cuda.synchronize()
@@ -36,7 +35,7 @@ for (M, N, K) in shapes:
                     bad += 1
                     print(f"MISMATCH M={M} N={N} K={K} epi={name} out{i} run{which} err={err:.4g} scale={scale:.4g}")
     if M * N <= 4096 * 1024:
-        h.clipa_debug_set(var, 0)
+        lib.debug_set(var, 0)
         o = ops.gemm_nt(a, w, bias).double()
         want = a.double() @ w.double().t() + bias.double()
         rel = ((o - want).abs().max() / want.abs().max()).item()

@@ -1,6 +1,6 @@
-"""Experiment harness: production clipa_gemm_nt vs an experimental kernel of clipa_amd/csrc/experiments/ that exports clipa_gemm_<name>
+"""Experiment harness: production clipa_gemm_nt vs an experimental kernel of tools/experiments/ that exports clipa_gemm_<name>
 with the same signature (nt4: four waves, gemm_nt4_four_waves.hip; nt6: A3/B2 operand ring, gemm_nt6_a3b2_ring.hip), linked into a
-VARIANT library by `tools/build_variant.sh <name> experiments/<file>.hip` and never into libclipa_hip.so: outputs compared bit for
+VARIANT library by `tools/build_variant.sh <name> tools/experiments/<file>.hip` and never into libclipa_hip.so: outputs compared bit for
 bit, interleaved timing.   python tools/gemm_nt4_ab.py [name=nt4] [M]"""
 import ctypes
 import json

@@ -1,8 +1,8 @@
 """Round-2 gemm_nt experiment: race screen + interleaved in-process A/B of the bf16-output kernels on the production
 launch shapes (ViT-L/16 @ 224, local batch 4096: M = 806 912; text tower M = 315 392).
     python tools/gemm_round2.py [--quick] > gpurun_out/gemm_round2.jsonl
-Variants are "nt:abl" pairs for clipa_debug_set: nt 11 LDS-window epilogue (round 1), 12 direct epilogue (13 / 14 /
-15 = the experiments of csrc/experiments/gemm_nt_round2.hip when pasted back); abl 1 = epilogue maths without
+Variants are "nt:abl" pairs for clipa_internal_debug_set: nt 11 LDS-window epilogue (round 1), 12 direct epilogue (13 / 14 /
+15 = the experiments of tools/experiments/gemm_nt_round2.hip when pasted back); abl 1 = epilogue maths without
 stores, 2 = main loop only."""
 import argparse, ctypes, json, os, sys
 import torch
@@ -36,12 +36,12 @@ def race_screen():
         bias = torch.randn(N, device=DEV)
         aux = torch.randn(M, N, device=DEV).to(bf16)
         for epi in ("bias", "gelu+pre", "res", "dact"):
-            h.clipa_debug_set(11, 0)
+            lib.debug_set(11, 0)
             ref = call(epi, a, w, bias, aux)
             ref = [t.clone() for t in (ref if isinstance(ref, tuple) else (ref,))]
             for v in (0,):
                 for rep in range(6):
-                    h.clipa_debug_set(v, 0)
+                    lib.debug_set(v, 0)
                     got = call(epi, a, w, bias, aux)
                     got = got if isinstance(got, tuple) else (got,)
                     for i, (x, y) in enumerate(zip(ref, got)):
@@ -50,7 +50,7 @@ def race_screen():
                             d = (x.float() - y.float()).abs()
                             emit(kind="MISMATCH", M=M, N=N, K=K, epi=epi, variant=v, rep=rep, out=i,
                                  n_bad=int((d > 0).sum()), max_err=float(d.max()))
-    h.clipa_debug_set(0, 0)
+    lib.debug_set(0, 0)
     emit(kind="race_screen", mismatches=bad)
     return bad
 
@@ -65,7 +65,7 @@ def bench(M, N, K, epis, variants, rounds, iters):
         times = {v: [] for v in variants}
         for rnd in range(rounds):
             for v in variants:
-                h.clipa_debug_set(v[0], v[1])
+                lib.debug_set(v[0], v[1])
                 call(epi, a, w, bias, aux)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -80,7 +80,7 @@ def bench(M, N, K, epis, variants, rounds, iters):
             med = t[len(t) // 2]
             emit(kind="bench", M=M, N=N, K=K, epi=epi, nt=v[0], abl=v[1], ms_med=round(med, 4), ms_min=round(t[0], 4),
                  tflops_med=round(2 * M * N * K / med / 1e9, 1), tflops_best=round(2 * M * N * K / t[0] / 1e9, 1))
-    h.clipa_debug_set(0, 0)
+    lib.debug_set(0, 0)
 
 
 def main():

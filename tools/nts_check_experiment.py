@@ -1,4 +1,4 @@
-"""Staggered-epilogue GEMM (clipa_debug_set variant 21 / 22) vs the production kernel: parity against fp64 on small forced
+"""Staggered-epilogue GEMM (clipa_internal_debug_set variant 21 / 22) vs the production kernel: parity against fp64 on small forced
 shapes, every epilogue, then an interleaved A/B on the production launch shapes.   python tools/nts_check.py [--quick]"""
 import json, os, sys
 import torch
@@ -27,13 +27,13 @@ def parity():
         lin = a[rows].double() @ b.double().T + bias.double()
         prev = None
         for rep in range(2):
-            h.clipa_debug_set(22, 0)
+            lib.debug_set(22, 0)
             o_bias = ops.gemm_nt(A, B, BIAS)
             o_add = ops.gemm_nt(A, B, BIAS, epi=ops.EPI_ADD, aux=AUX)
             o_act, o_pre = ops.gemm_nt(A, B, BIAS, epi=ops.EPI_ACT, act=0, want_pre=True)
             o_act1 = ops.gemm_nt(A, B, BIAS, epi=ops.EPI_ACT, act=0)
             o_dact = ops.gemm_nt(A, B, BIAS, epi=ops.EPI_DACT, act=0, aux=AUX)
-            h.clipa_debug_set(0, 0)
+            lib.debug_set(0, 0)
             torch.cuda.synchronize()
             res = {}
             res["bias"] = worst(o_bias[rows.to(DEV)], lin, 2 ** -7, 2e-3)
@@ -76,10 +76,10 @@ def bench(quick):
         outs = {}
         for rnd in range(3):
             for var in (0, 21):
-                h.clipa_debug_set(var, 0)
+                lib.debug_set(var, 0)
                 outs[var] = f(); f()
                 t[var].append(timed(f))
-        h.clipa_debug_set(0, 0)
+        lib.debug_set(0, 0)
         o0 = outs[0][0] if isinstance(outs[0], tuple) else outs[0]
         o1 = outs[21][0] if isinstance(outs[21], tuple) else outs[21]
         diff = float((o0.float() - o1.float()).abs().max())

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <vector>
 #include "clipa_hip.h"
+#include "../../clipa_amd/csrc/internal_hooks.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
@@ -39,11 +40,12 @@ static const Epi EPIS[] = {{"bias", CLIPA_EPI_NONE, false, false}, {"gelu", CLIP
                            {"residual", CLIPA_EPI_ADD, false, true}, {"gelu_bwd", CLIPA_EPI_DACT, false, true}};
 
 int main(int argc, char** argv) {
+  setenv("CLIPA_DEBUG_HOOKS", "1", 1);   // csrc/internal_hooks.h: the experiment hooks are off in production processes
   const bool quick = argc > 1 && !strcmp(argv[1], "quick");
   struct Shape { long M, N, K; };
   std::vector<Shape> shapes = {{131584, 5120, 1280}, {131584, 1280, 5120}, {131584, 3840, 1280}, {131584, 1280, 1280}, {200704, 4096, 1024}, {78848, 768, 3072}, {4096, 512, 512}, {512, 256, 768}};
   if (quick) shapes = {{131584, 5120, 1280}, {131584, 1280, 5120}, {512, 256, 768}};
-  const int VARS[] = {1, 0};   // clipa_debug_set variant: 1 = gemm_nt_f8_kernel, 0 = default (gemm_f8a where eligible)
+  const int VARS[] = {1, 0};   // clipa_internal_debug_set variant: 1 = gemm_nt_f8_kernel, 0 = default (gemm_f8a where eligible)
   const int NV = 2;
   hipStream_t st;
   CK(hipStreamCreate(&st));
@@ -72,7 +74,7 @@ int main(int argc, char** argv) {
     for (const Epi& e : EPIS) {
       if (fmt == 1 && e.epi != CLIPA_EPI_NONE && e.epi != CLIPA_EPI_DACT) continue;     // e5m2 = gradient operand: the input-gradient GEMMs
       auto run = [&](int variant, int slot) {
-        clipa_debug_set(variant, 0);
+        clipa_internal_debug_set(variant, 0);
         const int rc = clipa_gemm_nt_f8(A8[fmt], B8, sa[fmt], sb, C[slot], e.pre ? C2[slot] : nullptr, bias, e.aux ? AUX : nullptr, M, N, K, K, K, N, N,
                                         0.75f, e.epi, 0, fmt, 0, st);
         if (rc) { printf("clipa_gemm_nt_f8 rc=%d: %s\n", rc, clipa_last_error()); exit(3); }
@@ -109,7 +111,7 @@ int main(int argc, char** argv) {
           for (long c = 0; c < N; ++c) if (cols[c]) printf(" %ld", c); printf("\n");
         }
         printf("{\"check\": \"bits\", \"M\": %ld, \"N\": %ld, \"K\": %ld, \"epi\": \"%s\", \"fmt_a\": %d, \"kernel\": %d, \"mismatches\": %llu, \"first\": %lld}\n", M, N, K, e.name, fmt,
-               clipa_debug_last_gemm(), h[0], h[0] ? (long long)h[1] : -1ll);
+               clipa_internal_last_gemm(), h[0], h[0] ? (long long)h[1] : -1ll);
         fflush(stdout);
       }
       // ---- timing: interleaved rounds ----
@@ -145,7 +147,7 @@ int main(int argc, char** argv) {
           const int v = VARS[vi];
           std::vector<float> t;
           for (int r = 0; r < 3; ++r) {
-            clipa_debug_set(v, 2);
+            clipa_internal_debug_set(v, 2);
             clipa_gemm_nt_f8(A8[fmt], B8, sa[fmt], sb, C[1], nullptr, bias, nullptr, M, N, K, K, K, N, N, 1.0f, 0, 0, fmt, 0, st);
             CK(hipEventRecord(e0, st));
             for (int k = 0; k < reps; ++k) clipa_gemm_nt_f8(A8[fmt], B8, sa[fmt], sb, C[1], nullptr, bias, nullptr, M, N, K, K, K, N, N, 1.0f, 0, 0, fmt, 0, st);
@@ -166,6 +168,6 @@ int main(int argc, char** argv) {
     for (int f = 0; f < 2; ++f) { CK(hipFree(A8[f])); CK(hipFree(sa[f])); }
     for (int i = 0; i < 2; ++i) { CK(hipFree(C[i])); CK(hipFree(C2[i])); }
   }
-  clipa_debug_set(0, 0);
+  clipa_internal_debug_set(0, 0);
   return 0;
 }

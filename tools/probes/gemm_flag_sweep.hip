@@ -1,5 +1,5 @@
 // Experiment harness (not part of the library): clipa_gemm_nt at the real launch shapes (M = 806 912) under a list of
-// clipa_debug_set experiment flags (`codes` x 16).  Flags the library still has: 64 = epilogue stores dropped by the bounds
+// clipa_internal_debug_set experiment flags (`codes` x 16).  Flags the library still has: 64 = epilogue stores dropped by the bounds
 // check, 128 = every tile stores to tile 0 (L2 hits).  Round 3 also ran it with kernel-side switches that were removed after
 // the measurement: workgroups of an XCD started out of phase (profiles/r03_gemm_nta_intra_xcd_stagger.jsonl) and 8 rows x
 // 128 B per store instruction (profiles/r03_gemm_nta_store_row_width_timing.jsonl).
@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <vector>
 #include "clipa_hip.h"
+#include "../../clipa_amd/csrc/internal_hooks.h"
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
 __global__ void fill_bf16(unsigned short* p, size_t n, unsigned seed, float scale) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -18,6 +19,7 @@ __global__ void fill_bf16(unsigned short* p, size_t n, unsigned seed, float scal
   }
 }
 int main() {
+  setenv("CLIPA_DEBUG_HOOKS", "1", 1);   // csrc/internal_hooks.h: the experiment hooks are off in production processes
   hipStream_t st; CK(hipStreamCreate(&st));
   struct Case { long M, N, K; int epi; const char* name; };
   const Case cases[] = {{806912, 4096, 1024, 0, "bias"}, {806912, 4096, 1024, 1, "gelu"}, {806912, 4096, 1024, 3, "dact"},
@@ -35,7 +37,7 @@ int main() {
     for (int code : codes) {
       std::vector<float> t;
       for (int r = 0; r < 3; ++r) {
-        clipa_debug_set(0, code << 4);
+        clipa_internal_debug_set(0, code << 4);
         if (clipa_gemm_nt(A, B, C, nullptr, bias, aux, s.M, s.N, s.K, s.K, s.K, s.N, s.N, 1.0f, s.epi, 0, 0, st)) { printf("gemm failed: %s\n", clipa_last_error()); return 3; }
         CK(hipEventRecord(e0, st));
         for (int k = 0; k < 2; ++k) clipa_gemm_nt(A, B, C, nullptr, bias, aux, s.M, s.N, s.K, s.K, s.K, s.N, s.N, 1.0f, s.epi, 0, 0, st);
@@ -45,9 +47,9 @@ int main() {
       std::sort(t.begin(), t.end());
       printf(", \"s%d\": %.1f", code, 2.0 * s.M * s.N * s.K / (t[1] * 1e-3) / 1e12);
     }
-    printf(", \"last_gemm\": %d}\n", clipa_debug_last_gemm()); fflush(stdout);
+    printf(", \"last_gemm\": %d}\n", clipa_internal_last_gemm()); fflush(stdout);
     CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(bias)); if (aux) CK(hipFree(aux));
   }
-  clipa_debug_set(0, 0);
+  clipa_internal_debug_set(0, 0);
   return 0;
 }

@@ -1,11 +1,12 @@
 // Experiment (not part of the library): tile-group size (A panels per XCD group) of the persistent NT kernels at the real
-// launch shapes, M = 806 912.  clipa_debug_set flags bits 20..25 override nt_group_size.
+// launch shapes, M = 806 912.  clipa_internal_debug_set flags bits 20..25 override nt_group_size.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 #include "clipa_hip.h"
+#include "../../clipa_amd/csrc/internal_hooks.h"
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
 __global__ void fill_bf16(unsigned short* p, size_t n, unsigned seed, float scale) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -14,6 +15,7 @@ __global__ void fill_bf16(unsigned short* p, size_t n, unsigned seed, float scal
   }
 }
 int main() {
+  setenv("CLIPA_DEBUG_HOOKS", "1", 1);   // csrc/internal_hooks.h: the experiment hooks are off in production processes
   hipStream_t st; CK(hipStreamCreate(&st));
   struct Shape { long M, N, K; };
   const Shape shapes[] = {{806912, 4096, 1024}, {806912, 1024, 4096}, {806912, 3072, 1024}, {806912, 1024, 1024}};
@@ -28,7 +30,7 @@ int main() {
     for (int gm : gms) {
       std::vector<float> t;
       for (int r = 0; r < 3; ++r) {
-        clipa_debug_set(0, gm << 20);
+        clipa_internal_debug_set(0, gm << 20);
         clipa_gemm_nt(A, B, C, nullptr, bias, nullptr, s.M, s.N, s.K, s.K, s.K, s.N, s.N, 1.0f, 0, 0, 0, st);
         CK(hipEventRecord(e0, st));
         for (int k = 0; k < 2; ++k) clipa_gemm_nt(A, B, C, nullptr, bias, nullptr, s.M, s.N, s.K, s.K, s.K, s.N, s.N, 1.0f, 0, 0, 0, st);
@@ -41,6 +43,6 @@ int main() {
     printf("}\n"); fflush(stdout);
     CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(bias));
   }
-  clipa_debug_set(0, 0);
+  clipa_internal_debug_set(0, 0);
   return 0;
 }

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <vector>
 #include "clipa_hip.h"
+#include "../../clipa_amd/csrc/internal_hooks.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
@@ -39,11 +40,12 @@ static const Epi EPIS[] = {{"bias", CLIPA_EPI_NONE, false, false}, {"gelu", CLIP
                            {"residual", CLIPA_EPI_ADD, false, true}, {"gelu_bwd", CLIPA_EPI_DACT, false, true}};
 
 int main(int argc, char** argv) {
+  setenv("CLIPA_DEBUG_HOOKS", "1", 1);   // csrc/internal_hooks.h: the experiment hooks are off in production processes
   const bool quick = argc > 1 && !strcmp(argv[1], "quick");
   struct Shape { long M, N, K; };
   std::vector<Shape> shapes = {{200704, 4096, 1024}, {200704, 1024, 4096}, {200704, 3072, 1024}, {200704, 1024, 1024}, {78848, 768, 3072}, {4096, 512, 256}, {512, 256, 384}};
   if (quick) shapes = {{200704, 4096, 1024}, {200704, 1024, 4096}, {512, 256, 384}};
-  const int VARS[] = {1, 2, 5, 6};   // clipa_debug_set variant: 1 = gemm_nt2, 2 + s = gemm_nta schedule s (0, 3, 4 are compiled in)
+  const int VARS[] = {1, 2, 5, 6};   // clipa_internal_debug_set variant: 1 = gemm_nt2, 2 + s = gemm_nta schedule s (0, 3, 4 are compiled in)
   const int NV = 4;
   hipStream_t st;
   CK(hipStreamCreate(&st));
@@ -63,7 +65,7 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(st));
     for (const Epi& e : EPIS) {
       auto run = [&](int variant, int slot) {
-        clipa_debug_set(variant, 0);
+        clipa_internal_debug_set(variant, 0);
         const int rc = clipa_gemm_nt(A, B, C[slot], e.pre ? C2[slot] : nullptr, bias, e.aux ? AUX : nullptr, M, N, K, K, K, N, N, 1.0f, e.epi, 0, 0, st);
         if (rc) { printf("clipa_gemm_nt rc=%d: %s\n", rc, clipa_last_error()); exit(3); }
       };
@@ -119,7 +121,7 @@ int main(int argc, char** argv) {
           const int v = VARS[vi];
           std::vector<float> t;
           for (int r = 0; r < 3; ++r) {
-            clipa_debug_set(v, 2);
+            clipa_internal_debug_set(v, 2);
             clipa_gemm_nt(A, B, C[1], nullptr, bias, nullptr, M, N, K, K, K, N, N, 1.0f, 0, 0, 0, st);
             CK(hipEventRecord(e0, st));
             for (int k = 0; k < reps; ++k) clipa_gemm_nt(A, B, C[1], nullptr, bias, nullptr, M, N, K, K, K, N, N, 1.0f, 0, 0, 0, st);
@@ -139,6 +141,6 @@ int main(int argc, char** argv) {
     CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(AUX)); CK(hipFree(bias));
     for (int i = 0; i < 2; ++i) { CK(hipFree(C[i])); CK(hipFree(C2[i])); }
   }
-  clipa_debug_set(0, 0);
+  clipa_internal_debug_set(0, 0);
   return 0;
 }

@@ -1,5 +1,5 @@
 // Experiment harness (not part of the library): clipa_gemm_tn at production shapes under the work-order flags of
-// clipa_debug_set (0 = the library's choice, 4096 = slice-per-XCD order forced, 8192 = tile-per-XCD order forced).
+// clipa_internal_debug_set (0 = the library's choice, 4096 = slice-per-XCD order forced, 8192 = tile-per-XCD order forced).
 // Build:  hipcc --offload-arch=gfx950 -O2 -I include tools/probes/gemm_tn_order_sweep.hip -o tools/probes/gemm_tn_order_sweep -Lclipa_amd/lib -lclipa_hip -Wl,-rpath,'$ORIGIN/../../clipa_amd/lib'
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <vector>
 #include "clipa_hip.h"
+#include "../../clipa_amd/csrc/internal_hooks.h"
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
 __global__ void fill_bf16(unsigned short* p, size_t n, unsigned seed, float scale) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -15,6 +16,7 @@ __global__ void fill_bf16(unsigned short* p, size_t n, unsigned seed, float scal
   }
 }
 int main() {
+  setenv("CLIPA_DEBUG_HOOKS", "1", 1);   // csrc/internal_hooks.h: the experiment hooks are off in production processes
   hipStream_t st; CK(hipStreamCreate(&st));
   struct Shape { long M, R, C; };
   const Shape shapes[] = {{526336, 1280, 5120}, {526336, 5120, 1280}, {526336, 3840, 1280}, {526336, 1280, 1280},
@@ -25,12 +27,12 @@ int main() {
     CK(hipMalloc(&P, (size_t)s.M * s.R * 2)); CK(hipMalloc(&Q, (size_t)s.M * s.C * 2)); CK(hipMalloc(&out, (size_t)s.R * s.C * 4)); CK(hipMalloc(&cs, s.R * 4));
     fill_bf16<<<2048, 256, 0, st>>>(P, (size_t)s.M * s.R, 1u, 1.0f); fill_bf16<<<2048, 256, 0, st>>>(Q, (size_t)s.M * s.C, 2u, 1.0f);
     int64_t wsb = 0;
-    for (int f : {0, 4096, 8192}) { clipa_debug_set(0, f); int64_t ns; wsb = std::max(wsb, clipa_gemm_tn_workspace(s.M, s.R, s.C, &ns)); }
+    for (int f : {0, 4096, 8192}) { clipa_internal_debug_set(0, f); int64_t ns; wsb = std::max(wsb, clipa_gemm_tn_workspace(s.M, s.R, s.C, &ns)); }
     CK(hipMalloc(&ws, wsb));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     printf("{\"M\": %ld, \"R\": %ld, \"C\": %ld", s.M, s.R, s.C);
     for (int f : flags) {
-      clipa_debug_set(0, f);
+      clipa_internal_debug_set(0, f);
       int64_t ns = 0; clipa_gemm_tn_workspace(s.M, s.R, s.C, &ns);
       std::vector<float> t;
       for (int r = 0; r < 3; ++r) {
@@ -46,6 +48,6 @@ int main() {
     printf("}\n"); fflush(stdout);
     CK(hipFree(P)); CK(hipFree(Q)); CK(hipFree(out)); CK(hipFree(cs)); CK(hipFree(ws));
   }
-  clipa_debug_set(0, 0);
+  clipa_internal_debug_set(0, 0);
   return 0;
 }

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <vector>
 #include "clipa_hip.h"
+#include "../../clipa_amd/csrc/internal_hooks.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
@@ -42,6 +43,7 @@ __global__ void max_diff(const float* a, const float* b, size_t n, float* out) {
 }
 
 int main(int argc, char** argv) {
+  setenv("CLIPA_DEBUG_HOOKS", "1", 1);   // csrc/internal_hooks.h: the experiment hooks are off in production processes
   const bool quick = argc > 1 && !strcmp(argv[1], "quick");
   struct Shape { long M, R, C; };
   std::vector<Shape> shapes = {{200704, 4096, 1024}, {200704, 1024, 4096}, {200704, 3072, 1024}, {200704, 1024, 1024}, {78848, 3072, 768}, {78848, 768, 3072}, {78848, 768, 768}, {2048, 256, 512}};
@@ -71,7 +73,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpyAsync(ref.data(), d_ref, NS * 8, hipMemcpyDeviceToHost, st));
     CK(hipStreamSynchronize(st));
     auto run = [&](int v, int slot) {
-      clipa_debug_set(0, flags[v]);
+      clipa_internal_debug_set(0, flags[v]);
       const int rc = clipa_gemm_tn(P, Q, out[slot], csum[slot], M, R, C, R, C, 0, ws, wsb, st);
       if (rc) { printf("clipa_gemm_tn rc=%d: %s\n", rc, clipa_last_error()); exit(3); }
     };
@@ -99,7 +101,7 @@ int main(int argc, char** argv) {
         CK(hipStreamSynchronize(st));
       }
       printf("{\"check\": \"values\", \"kernel\": %d, \"M\": %ld, \"R\": %ld, \"C\": %ld, \"variant\": %d, \"nan\": %d, \"worst_rel_err_vs_fp64\": %.3g, \"worst_colsum_rel_err\": %.3g, \"max_abs_diff_vs_old\": %.3g, \"max_abs\": %.3g}\n",
-             clipa_debug_last_gemm(), M, R, C, v, nan, worst, worst_cs, md[0], md[1]);
+             clipa_internal_last_gemm(), M, R, C, v, nan, worst, worst_cs, md[0], md[1]);
       fflush(stdout);
     }
     if (M >= 50000) {
@@ -132,7 +134,7 @@ int main(int argc, char** argv) {
       for (int a = 0; a < 3; ++a) {
         std::vector<float> tt;
         for (int r = 0; r < 3; ++r) {
-          clipa_debug_set(0, ab[a]);
+          clipa_internal_debug_set(0, ab[a]);
           clipa_gemm_tn(P, Q, out[1], csum[1], M, R, C, R, C, 0, ws, wsb, st);
           CK(hipEventRecord(e0, st));
           for (int k = 0; k < reps; ++k) clipa_gemm_tn(P, Q, out[1], csum[1], M, R, C, R, C, 0, ws, wsb, st);
@@ -145,12 +147,12 @@ int main(int argc, char** argv) {
         std::sort(tt.begin(), tt.end());
         printf(", \"%s_tflops\": %.1f", a == 0 ? "normal" : a == 1 ? "no_fetch" : "l2_resident", 2.0 * M * R * C / (tt[1] * 1e-3) / 1e12);
       }
-      printf(", \"kernel\": %d}\n", clipa_debug_last_gemm());
+      printf(", \"kernel\": %d}\n", clipa_internal_last_gemm());
       fflush(stdout);
     }
     CK(hipFree(P)); CK(hipFree(Q)); CK(hipFree(ws));
     for (int i = 0; i < 2; ++i) { CK(hipFree(out[i])); CK(hipFree(csum[i])); }
   }
-  clipa_debug_set(0, 0);
+  clipa_internal_debug_set(0, 0);
   return 0;
 }

@@ -1,4 +1,4 @@
-"""In-process interleaved A/B of the gemm_tn kernels / work orders (clipa_debug_set flags: 1024 force the 16x16x32
+"""In-process interleaved A/B of the gemm_tn kernels / work orders (clipa_internal_debug_set flags: 1024 force the 16x16x32
 kernel, 2048 force the ping-pong kernel, 4096 slice-per-XCD work order).   python tools/tn_ab.py [M]"""
 import ctypes, json, os, sys
 import torch
@@ -17,7 +17,7 @@ for (M, R, C) in SHAPES:
     times = {a: [] for a in ABLS}
     for rnd in range(5):
         for abl in ABLS:
-            h.clipa_debug_set(0, abl)
+            lib.debug_set(0, abl)
             o = ops.gemm_tn(p, q, bf16, want_colsum=True); torch.cuda.synchronize()
             outs[abl] = o
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -25,7 +25,7 @@ for (M, R, C) in SHAPES:
             for _ in range(3): ops.gemm_tn(p, q, bf16, want_colsum=True)
             e1.record(); torch.cuda.synchronize()
             times[abl].append(e0.elapsed_time(e1) / 3)
-    h.clipa_debug_set(0, 0)
+    lib.debug_set(0, 0)
     same = all(torch.allclose(outs[0][0].float(), outs[a][0].float(), rtol=2e-2, atol=2e-2) and torch.allclose(outs[0][1], outs[a][1], rtol=1e-4, atol=1e-2) for a in ABLS)
     for abl in ABLS:
         t = sorted(times[abl]); med = t[len(t) // 2]
