@@ -66,7 +66,8 @@ def _all_gather_bf16(local, world_size, group=None):
 def _reduce_scatter_fused(full, world_size, group=None):
     """reduce-scatter(SUM) [W*B, 2E] f32 -> [B, 2E]: backward of the differentiable all-gather."""
     rows = full.shape[0] // world_size
-    if dist.get_backend(group) == "gloo":   # test harnesses only: gloo has no reduce-scatter, all-reduce and keep our slice
+    if dist.get_backend(group) == "gloo" and full.is_cuda:   # 2-ranks-on-one-GPU test harness only: gloo reduce-scatters CPU
+        # tensors (the 2- and 8-rank CPU tests walk the production call below), not device tensors: all-reduce, keep our slice
         full = full.contiguous().clone()
         dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
         r = dist.get_rank(group)

@@ -37,7 +37,7 @@ class _Bucket:
 class ShardedAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_clip_norm=None, clamp=None,
                  process_group=None, bucket_bytes=256 << 20, exchange="reduce_scatter", broadcast_parameters=True,
-                 force_collectives=False):
+                 force_collectives=False, tensor_collectives=None):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         if exchange not in ("reduce_scatter", "all_to_all"):
             raise ValueError(f"exchange={exchange!r}: 'reduce_scatter' or 'all_to_all'")
@@ -48,7 +48,10 @@ class ShardedAdamW(torch.optim.Optimizer):
         self.world = dist.get_world_size(process_group) if self.dist_on else 1
         self.rank = dist.get_rank(process_group) if self.dist_on else 0
         # torch's gloo backend (CPU tests, 2 ranks on one GPU) lacks reduce_scatter / *_into_tensor: same maths via all_reduce
-        self._tensor_collectives = self.dist_on and dist.get_backend(process_group) == "nccl"
+        # (tensor_collectives=True walks the production calls - reduce_scatter_tensor / all_to_all_single / all_gather_into_tensor -
+        # on a backend that has them for the tensors at hand: gloo with CPU tensors, the 8-rank CPU tests)
+        self._tensor_collectives = (self.dist_on and dist.get_backend(process_group) == "nccl") if tensor_collectives is None \
+            else bool(tensor_collectives) and self.dist_on
         # force_collectives: issue every collective even in a 1-rank group (they degenerate to copies) - the pre-flight of
         # the RCCL call sequence on a single GPU (tests, bench.py under CLIPA_BENCH_FORCE_DIST=1)
         self._collect = self.world > 1 or (bool(force_collectives) and self.dist_on)

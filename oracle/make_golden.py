@@ -147,11 +147,10 @@ def _dist_worker(rank, world, port, B, E, q):
     dist.destroy_process_group()
 
 
-def run_dist(world=2, B=8, E=16):
+def run_dist(world=2, B=8, E=16, port=29731):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29731
     procs = [ctx.Process(target=_dist_worker, args=(r, world, port, B, E, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -166,8 +165,8 @@ def run_dist(world=2, B=8, E=16):
             arrays[f"gi_{key}_r{rank}"] = gi
             arrays[f"gt_{key}_r{rank}"] = gt
             arrays[f"gs_{key}_r{rank}"] = gs
-    np.savez_compressed(os.path.join(OUT, "dist_loss_w2.npz"), **arrays)
-    print("dist_loss_w2: losses", {k: v for k, v in arrays.items() if k.startswith("loss_")})
+    np.savez_compressed(os.path.join(OUT, f"dist_loss_w{world}.npz"), **arrays)
+    print(f"dist_loss_w{world}: losses", {k: v for k, v in arrays.items() if k.startswith("loss_")})
 
 
 def main():
@@ -183,6 +182,9 @@ def main():
             run_case(name, dict(spec, cfg=full_cfg(spec)), ref_model, ref_loss)
     if not only or "dist_loss_w2" in only:
         run_dist()
+    if not only or "dist_loss_w8" in only:
+        # the node size of BASELINE configs 3-5: eight ranks, an odd per-rank batch (labels offset by 3 * rank)
+        run_dist(world=8, B=3, E=16, port=29733)
 
 
 if __name__ == "__main__":

@@ -1,12 +1,13 @@
-"""world_size-2 gloo test (CPU) of the multi-rank glue of clipa_amd.loss: bf16 feature all-gathers,
+"""world_size-2 and world_size-8 gloo tests (CPU) of the multi-rank glue of clipa_amd.loss: bf16 feature all-gathers,
 label offsets, the four local_loss x gather_with_grad variants and the reduce-scatter backward - checked
-against tests/golden/dist_loss_w2.npz, which was produced by the REAL reference ClipLoss under a 2-rank
-gloo group.  The HIP kernels cannot run here, so - in this test process only - `clipa_amd.loss.ops` is
+against tests/golden/dist_loss_w{2,8}.npz, which were produced by the REAL reference ClipLoss under 2- and 8-rank
+gloo groups.  The HIP kernels cannot run here, so - in this test process only - `clipa_amd.loss.ops` is
 replaced by torch-CPU stand-ins built from the oracle maths; the product never takes that route."""
 import os
 import types
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -54,12 +55,13 @@ def _cpu_ops():
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sys
     sys.path.insert(0, ROOT)
     import clipa_amd.loss as L
     L.ops = _cpu_ops()
-    z = np.load(os.path.join(ROOT, "tests", "golden", "dist_loss_w2.npz"))
+    z = np.load(os.path.join(ROOT, "tests", "golden", f"dist_loss_w{world}.npz"))
     B = int(z["B"])
     res = {}
     for local_loss in (True, False):
@@ -76,18 +78,23 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_cliploss_two_ranks_gloo_matches_reference():
-    world = 2
+@pytest.mark.parametrize("world,port", [(2, 29741), (8, 29743)])
+def test_cliploss_gloo_ranks_match_reference(world, port):
+    """2 ranks (B = 8 each) and the node size of BASELINE configs 3-5: 8 ranks with an ODD per-rank batch of 3 (label offset
+    3 * rank, 24 gathered rows), every local_loss x gather_with_grad variant, against the REAL reference's ClipLoss under the
+    same gloo groups (oracle/make_golden.py run_dist).  On CPU tensors gloo runs the production collectives
+    (all_gather_into_tensor on uint8 views, reduce_scatter_tensor of the fused fp32 gradient)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, 29741, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=300) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    z = np.load(os.path.join(ROOT, "tests", "golden", "dist_loss_w2.npz"))
+    z = np.load(os.path.join(ROOT, "tests", "golden", f"dist_loss_w{world}.npz"))
+    assert int(z["world"]) == world
     for rank in range(world):
         for key, (loss, gi, gt, gs) in got[rank].items():
             # bf16 features / bf16 dlogits in the engine's data path -> bf16-level tolerance

@@ -87,6 +87,24 @@ def test_checkpoint_interchange_with_live_reference(tmp_path):
     assert big.visual.positional_embedding.shape[0] == 197
 
 
+def test_two_resolution_handoff_matches_reference_golden(tmp_path):
+    """BASELINE config 5's hand-off on the host side (the part that needs no GPU): the factory loads an 84 px / sin-cos / GAP /
+    context-16 checkpoint, written as training/main.py:436-468 writes it, into the 224 px / learnable / context-32 model;
+    the resized tables equal the REAL reference's (tests/golden/handoff_S16_84_to_224.npz, oracle/make_handoff_golden.py) and
+    the oracle on the loaded weights reproduces the reference's features, loss and gradient digests of the same hand-off."""
+    from .conftest import Handoff
+    from oracle.make_handoff_golden import write_checkpoint
+    h = Handoff(tmp_path)
+    m84 = h.phase1_model()
+    assert not m84.visual.positional_embedding.requires_grad and m84.visual.positional_embedding.shape[0] == 26
+    path = tmp_path / "epoch_1.pt"
+    write_checkpoint(m84.state_dict(), path)
+    big = clipa_amd.create_model(h.NAME224, pretrained=str(path), force_image_size=224, pos_embed="learnable")
+    assert big.visual.positional_embedding.requires_grad
+    ref, loss, _, _ = h.check_against_reference(big)
+    assert "visual.positional_embedding" in ref and abs(loss - float(h.t("loss"))) < 3e-5
+
+
 def test_capi_exports_every_declared_symbol():
     """The shared library loads here (no GPU needed) and exports every function of include/clipa_hip.h."""
     header = open(os.path.join(ROOT, "include", "clipa_hip.h")).read()

@@ -89,14 +89,15 @@ def test_single_process_equals_fused_adamw(cpu_ops_swapped):
         assert torch.equal(p, q)
 
 
-def _toy_worker(rank, world, port, q, exchange, mode="no_sync"):
+def _toy_worker(rank, world, port, q, exchange, mode="no_sync", tensor_collectives=None):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     _swap()
     from clipa_amd.zero import ShardedAdamW
     m = _toy(seed=rank)                                                # different initial weights: rank 0's must win
-    opt = ShardedAdamW(_groups(m), grad_clip_norm=0.5, bucket_bytes=1024, exchange=exchange, **HP)
+    opt = ShardedAdamW(_groups(m), grad_clip_norm=0.5, bucket_bytes=1024, exchange=exchange, tensor_collectives=tensor_collectives,
+                       **HP)
     torch.manual_seed(100 + rank)
     xs = [torch.randn(16, 24) for _ in range(3)]
     for step in range(2):
@@ -138,13 +139,20 @@ def _spawn(target, world, port, *args):
     return got
 
 
-@pytest.mark.parametrize("mode,port", [("no_sync", 29771), ("plain", 29775), ("sync_then_no_sync", 29777)])
-def test_two_rank_sharded_step_equals_adamw_on_averaged_gradient(mode, port):
+@pytest.mark.parametrize("mode,port,world,exchange,tc", [
+    ("no_sync", 29771, 2, "reduce_scatter", None), ("plain", 29775, 2, "reduce_scatter", None),
+    ("sync_then_no_sync", 29777, 2, "reduce_scatter", None),
+    # the node size of the BASELINE configurations, on the PRODUCTION collectives (gloo has them for CPU tensors): buckets of
+    # 1 KiB whose padded sizes are multiples of 8 x 8 elements - i.e. the tail-handling RCCL's AVG path got wrong in round 2
+    ("plain", 29779, 8, "reduce_scatter", True), ("no_sync", 29781, 8, "all_to_all", True),
+    ("sync_then_no_sync", 29783, 8, "all_to_all", True)])
+def test_sharded_step_equals_adamw_on_averaged_gradient(mode, port, world, exchange, tc):
     """Three ways of accumulating three micro-batches before one step - inside no_sync (one exchange), plain repeated
     backward() as the reference's accum_freq loop does (every completed round re-exchanges the cumulative gradient), and
-    an exchange that later backwards make stale - all equal AdamW on the rank-averaged accumulated gradient."""
-    world = 2
-    got = _spawn(_toy_worker, world, port, "reduce_scatter", mode)
+    an exchange that later backwards make stale - all equal AdamW on the rank-averaged accumulated gradient; with 2 ranks
+    (gloo's all-reduce emulation, as the 2-ranks-on-one-GPU tests use) and with 8 ranks on reduce_scatter_tensor /
+    all_to_all_single + reduce_shards / all_gather_into_tensor."""
+    got = _spawn(_toy_worker, world, port, exchange, mode, tc)
     _swap()
     try:
         from clipa_amd.optim import AdamW
@@ -162,10 +170,12 @@ def test_two_rank_sharded_step_equals_adamw_on_averaged_gradient(mode, port):
         ref_m = {k: v["exp_avg"].numpy() for k, v in opt.state_dict()["state"].items()}
     finally:
         _unswap()
-    for a, b, r in zip(got[0][0], got[1][0], ref):
-        assert np.array_equal(a, b), "ranks hold different parameters after the all-gather"
+    for k in range(1, world):
+        for a, b in zip(got[0][0], got[k][0]):
+            assert np.array_equal(a, b), f"ranks 0 and {k} hold different parameters after the all-gather"
+        assert abs(got[0][1] - got[k][1]) < 1e-6
+    for a, r in zip(got[0][0], ref):
         assert np.allclose(a, r, rtol=2e-5, atol=2e-6)
-    assert abs(got[0][1] - got[1][1]) < 1e-6
     for k, v in ref_m.items():
         assert np.allclose(got[0][2][k], v, rtol=2e-5, atol=1e-7), k   # consolidated moments = the unsharded optimizer's
 
