@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
+PEAK_HBM_TBPS = 8.0           # HBM3E peak of the same guide
 PEAK_FP8_TFLOPS = 5000.0      # dense fp8 peak on v_mfma_f32_16x16x128_f8f6f4 (same guide: ~5 PF dense)
 # the MFMA-bound kernels a step can be dominated by: profile key -> (peak TFLOP/s, description)
 ROOFLINE_KERNELS = {
@@ -59,6 +60,20 @@ def train_gflop_per_pair(cfg, S, ctx):
     Dt = t["width"]
     fwd += t["layers"] * ctx * (24 * Dt * Dt + 4 * ctx * Dt) + 2 * Dt * E
     return 3.0 * fwd / 1e9
+
+
+def kernel_entry(v, steps):
+    """One line of the `kernels` block: MFMA-bound kernels (algorithmic FLOPs known) report TFLOP/s, HBM-bound ones (LayerNorm,
+    row quantisers, patch gather, activation re-materialisation, crops) their algorithmic bytes per second and the fraction
+    of the 8 TB/s HBM3E peak (MI355X_MICROARCH.md; ~6.3 TB/s is what a streaming kernel reaches on this part)."""
+    e = {"launches": v["launches"], "ms_per_step": round(v["ms"] / steps, 2)}
+    if v["work"] > 0:
+        e["tflops"] = round(v["work"] / max(v["ms"], 1e-9) / 1e9, 1)
+    elif v.get("bytes", 0) > 0:
+        gbps = v["bytes"] / max(v["ms"], 1e-9) / 1e6
+        e["hbm_gbps"] = round(gbps, 1)
+        e["hbm_frac"] = round(gbps / (PEAK_HBM_TBPS * 1e3), 4)
+    return e
 
 
 def plan_keep(budget, layers_v, layers_t, mv_b, mt_b, lv_b, lt_b):
@@ -142,7 +157,7 @@ def main():
                          "configs[3]: bf16 weights / activations, e4m3 operands for the block GEMMs (forward + input gradient)")
     ap.add_argument("--keep-blocks", default="auto", help="'auto' or 'LV,LT[,MV,MT]': light-kept (and medium-kept) blocks per tower (image, text)")
     ap.add_argument("--keep-fraction", type=float, default=None,
-                    help="share of the free HBM 'auto' may spend (default 0.93 single process, 0.86 with several ranks: no OOM back-off there)")
+                    help="share of the free HBM 'auto' may spend (default 0.93 single process, 0.90 with several ranks; a trial step + vote backs the plan off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shapes", action="store_true", help="also report time and TF/s per GEMM / attention shape (stderr)")
     ap.add_argument("--accum-freq", type=int, default=1,
@@ -268,6 +283,7 @@ def main():
         model.visual.transformer.medium_blocks, model.transformer.medium_blocks = mv, mt
 
     keep_v = keep_t = med_v = med_t = 0
+    backoffs = 0
     L_img = (args.image_size // cfg["vision_cfg"]["patch_size"]) ** 2 + 1
     vt, tt = model.visual.transformer, model.transformer
     warm = args.warmup
@@ -277,7 +293,9 @@ def main():
         step()                                   # one extra untimed all-recompute step, only to measure its peak
         torch.cuda.synchronize()                 # (under DDP this peak already contains the reducer's buckets)
         peak = torch.cuda.max_memory_allocated(dev)
-        frac = args.keep_fraction if args.keep_fraction is not None else (0.86 if dist_on else 0.93)
+        # several ranks: a little less than alone (RCCL's channel buffers and the gathered features grow with the world size;
+        # the trial below is collective-free), and the vote after the trial backs every rank off together if it was too much
+        frac = args.keep_fraction if args.keep_fraction is not None else (0.90 if dist_on else 0.93)
         budget0 = int(frac * (total_mem - peak)) - (6 << 30)
         if dist_on:
             budget0 = agree_budget(budget0, dev)
@@ -291,21 +309,52 @@ def main():
             return plan_keep(budget, cfg["vision_cfg"]["layers"], cfg["text_cfg"]["layers"], mv_b, mt_b, lv_b, lt_b)
 
         keep_v, keep_t, med_v, med_t = plan(budget0)
-        if not dist_on:
-            # trial step under the plan; an allocator-fragmentation OOM shrinks the budget instead of failing the run.
-            # Single process only: a rank that backs off alone would leave its peers inside a DDP all-reduce - with
-            # several ranks the smaller keep fraction above is the safety margin instead.
-            for attempt in range(4):
-                set_keep(keep_v, keep_t, med_v, med_t)
-                try:
-                    step()
-                    torch.cuda.synchronize()
-                    break
-                except torch.OutOfMemoryError:
-                    opt.zero_grad(set_to_none=True)
-                    torch.cuda.empty_cache()
-                    budget0 -= 12 << 30
-                    keep_v, keep_t, med_v, med_t = plan(budget0)
+
+        # Trial step under the plan; an allocator-fragmentation OOM shrinks the budget instead of failing the run.  With
+        # several ranks a rank must never run out of memory INSIDE a collective (its peers would wait for it forever), so
+        # the trial there is collective-free: forward + backward of the unwrapped model against a one-rank loss, the early
+        # gather unbound, the sharded optimizer's exchange inside no_sync(), no optimizer step (the reducer of DDP ignores
+        # gradient hooks of a forward it did not see) - the same activation memory as the real step.  Then every rank votes
+        # (MIN all-reduce): all ranks keep the same blocks, and all of them back off if any of them could not fit the plan.
+        def trial():
+            if not dist_on:
+                step()
+                torch.cuda.synchronize()
+                return
+            import contextlib
+            partner, model._gather_partner = model._gather_partner, None
+            try:
+                with (opt.no_sync() if args.optimizer == "sharded" else contextlib.nullcontext()):
+                    local_loss = clipa_amd.ClipLoss()
+                    for im, tx in zip(images.chunk(A), texts.chunk(A)):
+                        out = model(im, tx)
+                        local_loss(**out, output_dict=True)["contrastive_loss"].backward()
+                torch.cuda.synchronize()
+            finally:
+                model._gather_partner = partner
+                opt.zero_grad(set_to_none=True)
+
+        backoffs = 0
+        for attempt in range(5):
+            set_keep(keep_v, keep_t, med_v, med_t)
+            ok = 1
+            try:
+                trial()
+            except torch.OutOfMemoryError:
+                ok = 0
+                opt.zero_grad(set_to_none=True)
+                torch.cuda.empty_cache()
+            if dist_on:
+                vote = torch.tensor([ok], device=dev, dtype=torch.int32)
+                dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+                ok = int(vote.item())
+            if ok:
+                break
+            backoffs += 1
+            budget0 -= 12 << 30
+            keep_v, keep_t, med_v, med_t = plan(budget0)
+        else:
+            keep_v = keep_t = med_v = med_t = 0        # five plans did not fit: fall back to the all-recompute step that did
     else:
         vals = [int(v) for v in args.keep_blocks.split(",")]
         keep_v, keep_t = vals[0], vals[1]
@@ -314,6 +363,9 @@ def main():
     for _ in range(warm):
         step()
     fence()
+    from clipa_amd import loss as loss_mod
+    if dist_on:
+        loss_mod.wait_timing_start()
     ops.profile_start(detail=args.shapes)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -321,6 +373,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     prof = ops.profile_stop()
+    gather_wait_ms = loss_mod.wait_timing_stop() / args.steps if dist_on else 0.0
     last_loss = float(loss)
     if dist_on:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -383,6 +436,15 @@ def main():
         except (RuntimeError, torch.OutOfMemoryError) as e:                      # the headline line must survive
             h2d = {"value": None, "error": str(e)[:200]}
 
+    mine = {"rank": rank, "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
+            "peak_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2**30, 1),
+            "alloc_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)),
+            "kernel_ms_per_step": round(sum(v["ms"] for k, v in prof.items() if "|" not in k) / args.steps, 2),
+            "gather_wait_ms_per_step": round(gather_wait_ms, 3)}
+    per_rank = [mine]
+    if dist_on:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         pairs_s = B * world * args.steps / elapsed
@@ -424,14 +486,19 @@ def main():
             "loss": round(last_loss, 4), "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
             "peak_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2**30, 1),
             "alloc_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)),
+            "keep_plan_backoffs": backoffs,
+            # what the step spends outside this library's kernels (rank 0): at one rank host gaps + optimizer glue, with several
+            # ranks additionally the EXPOSED part of the exchanges (gradient all-reduce tail, feature gathers); the wait of
+            # the compute stream for the feature gathers is event-timed separately (per_rank.gather_wait_ms_per_step)
+            "non_kernel_ms_per_step": round(ms - mine["kernel_ms_per_step"], 2),
+            "per_rank": per_rank,
             "roofline": {"bound": "mfma", "kernel": dom_desc, "achieved": round(achieved, 1),
                          "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": round(nt.get("bytes", 0.0) / max(nt["launches"], 1)),
                          "launches": nt["launches"],
                          "avg_launch_ms": round(nt["ms"] / max(nt["launches"], 1), 4)},
             "h2d_inclusive": h2d,
-            "kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 2),
-                            "tflops": round(v["work"] / max(v["ms"], 1e-9) / 1e9, 1)} for k, v in prof.items() if "|" not in k},
+            "kernels": {k: kernel_entry(v, args.steps) for k, v in prof.items() if "|" not in k},
         }
         if args.shapes:
             for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):

@@ -35,6 +35,25 @@ from . import ops
 bf16, f32 = torch.bfloat16, torch.float32
 
 _SIDE = {}                                    # device -> side stream (created once per device, never mutated afterwards)
+_WAITS = None                                 # bench instrumentation: [(event before, event after)] around the gather waits
+
+
+def wait_timing_start():
+    """bench.py: record a HIP event pair around every wait of the compute stream for a feature gather (the EXPOSED part of
+    the exchange: whatever the side stream has not finished by the time the loss needs the gathered rows)."""
+    global _WAITS
+    _WAITS = []
+
+
+def wait_timing_stop():
+    """-> total milliseconds the compute stream spent waiting for gathers since wait_timing_start()."""
+    global _WAITS
+    recs, _WAITS = _WAITS, None
+    if not recs:
+        return 0.0
+    torch.cuda.synchronize()
+    return float(sum(a.elapsed_time(b) for a, b in recs))
+
 
 
 def _side_stream(device):
@@ -105,9 +124,16 @@ class ClipLossFn(torch.autograd.Function):
                 i_all, i_ev = _all_gather_bf16(ib, world_size, group)
             if img.is_cuda:
                 cur = torch.cuda.current_stream()
+                if _WAITS is not None:
+                    before = torch.cuda.Event(enable_timing=True)
+                    before.record(cur)
                 for ev in (i_ev, t_ev):
                     if ev is not None:
                         cur.wait_event(ev)
+                if _WAITS is not None:
+                    after = torch.cuda.Event(enable_timing=True)
+                    after.record(cur)
+                    _WAITS.append((before, after))
         else:
             ib = ops.to_bf16(img)
             i_all, t_all = ib, tb

@@ -150,7 +150,8 @@ def layernorm_fwd_q8(x, gamma, beta, eps=1e-5, want_bf16=False):
     y = torch.empty(x.shape, device=x.device, dtype=bf16) if want_bf16 else None
     q = torch.empty(x.shape, device=x.device, dtype=u8)
     dq = torch.empty(rows, device=x.device, dtype=f32)
-    lib.call("clipa_layernorm_fwd_q8", _p(x), _p(gamma), _p(beta), _p(y), _p(q), _p(dq), rows, D, float(eps), _stream())
+    with _Timed("ln_fwd_q8", 0.0, float(rows) * D * (3 + (2 if want_bf16 else 0)), f"{rows},{D}"):
+        lib.call("clipa_layernorm_fwd_q8", _p(x), _p(gamma), _p(beta), _p(y), _p(q), _p(dq), rows, D, float(eps), _stream())
     return y, q, dq
 
 
@@ -214,8 +215,9 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=None):
     rows = x.numel() // D
     out_dtype = out_dtype or x.dtype
     y = torch.empty(x.shape, device=x.device, dtype=out_dtype)
-    lib.call("clipa_layernorm_fwd", _p(x), _p(gamma), _p(beta), _p(y), rows, D, float(eps),
-             int(x.dtype == f32), int(out_dtype == f32), _stream())
+    with _Timed("ln_fwd", 0.0, float(rows) * D * (x.element_size() + y.element_size()), f"{rows},{D}"):
+        lib.call("clipa_layernorm_fwd", _p(x), _p(gamma), _p(beta), _p(y), rows, D, float(eps),
+                 int(x.dtype == f32), int(out_dtype == f32), _stream())
     return y
 
 
@@ -234,8 +236,10 @@ def layernorm_bwd(x, gamma, dy, dres=None, eps=1e-5):
         dres = dres.contiguous()
         if dres.dtype != x.dtype:
             raise RuntimeError("layernorm_bwd: dres dtype must match x")
-    lib.call("clipa_layernorm_bwd", _p(x), _p(gamma), _p(dy), _p(dres), _p(dx), _p(dgamma), _p(dbeta), rows, D,
-             float(eps), int(x.dtype == f32), int(dy.dtype == f32), _p(ws), wsb, _stream())
+    nbytes = float(rows) * D * (2 * x.element_size() + dy.element_size() + (x.element_size() if dres is not None else 0))
+    with _Timed("ln_bwd", 0.0, nbytes, f"{rows},{D}"):
+        lib.call("clipa_layernorm_bwd", _p(x), _p(gamma), _p(dy), _p(dres), _p(dx), _p(dgamma), _p(dbeta), rows, D,
+                 float(eps), int(x.dtype == f32), int(dy.dtype == f32), _p(ws), wsb, _stream())
     return dx, dgamma, dbeta
 
 
@@ -295,7 +299,8 @@ def patchify(img, P, Kp, mean=None, std=None):
     normalize = mean is not None
     m3 = (ctypes.c_float * 3)(*([float(v) for v in mean] if normalize else [0, 0, 0]))
     s3 = (ctypes.c_float * 3)(*([float(v) for v in std] if normalize else [1, 1, 1]))
-    lib.call("clipa_patchify", _p(img), _p(out), B, S, P, Kp, dt, nhwc, int(normalize), m3, s3, _stream())
+    with _Timed("patchify", 0.0, float(img.numel()) * img.element_size() + 2.0 * out.numel(), f"{B},{S},{P}"):
+        lib.call("clipa_patchify", _p(img), _p(out), B, S, P, Kp, dt, nhwc, int(normalize), m3, s3, _stream())
     return out
 
 
@@ -522,7 +527,8 @@ def activation_fwd(x, act):
     _chk(x, bf16, "x")
     x = x.contiguous()
     out = torch.empty_like(x)
-    lib.call("clipa_activation_fwd", _p(x), _p(out), x.numel(), act, _stream())
+    with _Timed("activation_fwd", 0.0, 4.0 * x.numel()):
+        lib.call("clipa_activation_fwd", _p(x), _p(out), x.numel(), act, _stream())
     return out
 
 

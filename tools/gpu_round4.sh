@@ -1,0 +1,56 @@
+#!/bin/bash
+# Round-4 GPU sessions.  Usage: gpurun --timeout N -- 'bash tools/gpu_round4.sh [stage...]'
+set -u
+mkdir -p gpurun_out
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+R="$PWD"
+STAGES="${*:-newtests benchq}"
+for s in $STAGES; do
+  case $s in
+    alltests)
+      timeout 1800 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -s > gpurun_out/pytest_gpu.log 2>&1
+      echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log ;;
+    newtests)
+      timeout 1200 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py tests/test_fp8_gpu.py -m gpu -q --tb=short -p no:cacheprovider -s \
+        -k "${NEWTESTS_K:-gemm or bf16_mode or handoff or f8a or recompute}" > gpurun_out/pytest_new.log 2>&1
+      echo "pytest rc=$?" >> gpurun_out/pytest_new.log ;;
+    bench)
+      timeout 900 python bench.py --shapes > gpurun_out/bench.log 2>&1; echo "rc=$?" >> gpurun_out/bench.log ;;
+    benchq)
+      timeout 600 python bench.py --shapes --steps 3 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 ${BENCHQ_ARGS:-} > gpurun_out/benchq.log 2>&1; echo "rc=$?" >> gpurun_out/benchq.log ;;
+    benchdist)
+      # the multi-rank code path (RCCL group, DDP, vote-based keep plan, per-rank record) on one GPU
+      CLIPA_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29655 \
+        bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 ${BENCHDIST_ARGS:-} > gpurun_out/bench_dist1.log 2>&1; echo "rc=$?" >> gpurun_out/bench_dist1.log ;;
+    gemmab)
+      timeout 600 ./tools/probes/gemm_nta_ab ${GEMMAB_ARGS:-} > gpurun_out/gemm_nt_asm_ab.log 2>&1; echo "rc=$?" >> gpurun_out/gemm_nt_asm_ab.log ;;
+    tnab)
+      timeout 600 ./tools/probes/gemm_tna_ab ${GEMMAB_ARGS:-} > gpurun_out/gemm_tna_ab.log 2>&1; echo "rc=$?" >> gpurun_out/gemm_tna_ab.log ;;
+    fp8conv)
+      for seed in ${FP8CONV_SEEDS:-1 2}; do
+        timeout 600 python tools/fp8_convergence.py --steps 200 --batch 256 --lr ${FP8CONV_LR:-3e-4} --seed $seed --oracle-steps 0 > gpurun_out/fp8_convergence_seed$seed.jsonl 2> gpurun_out/fp8_convergence_seed$seed.err; echo "rc=$?" >> gpurun_out/fp8_convergence_seed$seed.err
+      done ;;
+    others)
+      timeout 400 python bench.py --model ViT-B-16 --steps 3 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 > gpurun_out/bench_b16.log 2>&1
+      for prec in bf16 fp8; do
+        timeout 500 python bench.py --model ViT-H-14 --batch 2048 --precision $prec --steps 2 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 --shapes > gpurun_out/bench_h14_$prec.log 2>&1
+      done
+      timeout 400 python bench.py --model ViT-L-16 --image-size 84 --steps 3 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 > gpurun_out/bench_l16_84.log 2>&1 ;;
+    smoke)
+      timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "rc=$?" >> gpurun_out/smoke.log ;;
+    stats)
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof" -o r04 -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 > "$R/gpurun_out/bench_prof.log" 2>&1)
+      db=$(find gpurun_out/prof -name '*.db' | head -1)
+      [ -n "$db" ] && python tools/rocpd_stats.py "$db" > gpurun_out/kernel_stats.csv 2>&1 ;;
+    pmcbench)
+      mkdir -p gpurun_out/pmcbench
+      for set in ${PMC_SETS:-FETCH_SIZE WRITE_SIZE}; do
+        (cd /tmp && timeout 400 rocprofv3 --pmc $set -d "$R/gpurun_out/pmcbench/$set" -o pmc -- \
+           python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 --keep-blocks ${PMC_KEEP:-0,0,24,4} > "$R/gpurun_out/pmcbench/$set.log" 2>&1)
+      done
+      python tools/pmc_summary.py gpurun_out/pmcbench gemm attn ln_ > gpurun_out/pmcbench_summary.txt 2>&1 ;;
+    *) echo "unknown stage $s" ;;
+  esac
+done
+ls -la gpurun_out | tail -30
