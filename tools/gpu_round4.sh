@@ -25,6 +25,10 @@ for s in $STAGES; do
         bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 ${BENCHDIST_ARGS:-} > gpurun_out/bench_dist1.log 2>&1; echo "rc=$?" >> gpurun_out/bench_dist1.log ;;
     gemmab)
       timeout 600 ./tools/probes/gemm_nta_ab ${GEMMAB_ARGS:-} > gpurun_out/gemm_nt_asm_ab.log 2>&1; echo "rc=$?" >> gpurun_out/gemm_nt_asm_ab.log ;;
+    flagsweep)
+      timeout 600 ./tools/probes/gemm_flag_sweep ${FLAGSWEEP_ARGS:-} > gpurun_out/gemm_flag_sweep.jsonl 2>&1; echo "rc=$?" >> gpurun_out/gemm_flag_sweep.jsonl ;;
+    storepol)
+      timeout 600 python tools/gemm_lib_ab.py clipa_amd/lib/libclipa_hip.so $(ls clipa_amd/lib/libclipa_var_st*.so) > gpurun_out/store_policy_ab.jsonl 2>&1; echo "rc=$?" >> gpurun_out/store_policy_ab.jsonl ;;
     tnab)
       timeout 600 ./tools/probes/gemm_tna_ab ${GEMMAB_ARGS:-} > gpurun_out/gemm_tna_ab.log 2>&1; echo "rc=$?" >> gpurun_out/gemm_tna_ab.log ;;
     fp8conv)
