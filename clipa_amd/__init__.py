@@ -11,6 +11,7 @@ from .model import (CLIP, CLIPTextCfg, CLIPVisionCfg, OPENAI_DATASET_MEAN, OPENA
                     get_2d_sincos_pos_embed, resize_pos_embed, resize_text_pos_embed)
 
 from .data import DeviceAugment, DevicePrefetcher
+from .transform import AugmentationCfg, image_transform
 from .zero import ShardedAdamW
 
 __version__ = "0.2.0"

@@ -3,8 +3,8 @@ create_model (factory.py:121-259), create_loss (factory.py:262-290), create_mode
 (factory.py:293-352), load_checkpoint (factory.py:99-118).
 
 Out of scope and rejected loudly: pretrained tags / HF hub download (network), timm / ResNet / CoCa /
-HF-text towers, torchscript, and the PIL/torchvision image transforms (host I/O; the engine takes the
-uint8 tensors the reference already moves to the device, train.py:187-197).
+HF-text towers, torchscript.  The two image transforms create_model_and_transforms returns are
+clipa_amd.transform.image_transform (host-side, Pillow only).
 """
 import logging
 from typing import Optional, Tuple, Union
@@ -128,8 +128,10 @@ def create_model_and_transforms(model_name: str, pretrained: Optional[str] = Non
                                 cache_dir: Optional[str] = None, output_dict: Optional[bool] = None,
                                 to_float_on_device: bool = False, pos_embed: str = None,
                                 interpolation: str = 'bicubic', square_resize_only: bool = False):
-    """Same signature as factory.py:293-352. The two returned transforms are None: image decoding /
-    augmentation is host-side PIL/torchvision work that stays with the reference's data pipeline."""
+    """Same signature and return value as factory.py:293-352: (model, preprocess_train, preprocess_val).  The transforms are
+    clipa_amd.transform.image_transform - the reference's open_clip/transform.py:91-214 restated on Pillow alone (torchvision,
+    which the reference builds them from, is not part of this image); they run on the host in the loader workers exactly like
+    the reference's.  The engine's own device-side pipeline is clipa_amd.data.DeviceAugment."""
     model = create_model(model_name, pretrained, precision=precision, device=device, jit=jit,
                          force_quick_gelu=force_quick_gelu, force_custom_text=force_custom_text,
                          force_patch_dropout=force_patch_dropout, force_image_size=force_image_size,
@@ -140,4 +142,12 @@ def create_model_and_transforms(model_name: str, pretrained: Optional[str] = Non
         model.visual.image_mean = image_mean
     if image_std is not None:
         model.visual.image_std = image_std
-    return model, None, None
+    from .transform import image_transform
+    image_mean = image_mean or getattr(model.visual, 'image_mean', None)
+    image_std = image_std or getattr(model.visual, 'image_std', None)
+    preprocess_train = image_transform(model.visual.image_size, is_train=True, mean=image_mean, std=image_std, aug_cfg=aug_cfg,
+                                       to_float_on_device=to_float_on_device)
+    preprocess_val = image_transform(model.visual.image_size, is_train=False, mean=image_mean, std=image_std,
+                                     to_float_on_device=to_float_on_device, interpolation=interpolation,
+                                     square_resize_only=square_resize_only)
+    return model, preprocess_train, preprocess_val

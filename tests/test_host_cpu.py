@@ -293,3 +293,37 @@ def test_gelu_polynomials():
     dg = F.Phi(x64) + x64 * F.phi(x64)
     errb = np.abs(F.gelu_grad32(xs, cb).astype(np.float64) - dg)
     assert errb.max() <= 3e-4 and errb[np.abs(xs) < 3].max() <= 2e-5
+
+
+def test_create_model_and_transforms_returns_reference_style_transforms():
+    """factory.py:293-352: (model, preprocess_train, preprocess_val); the transforms (open_clip/transform.py:91-214 on Pillow
+    alone) turn a PIL image into the tensor the trainer moves to the device: float CHW normalised, or uint8 CHW with
+    to_float_on_device (train.py:191-197).  The eval transform is checked against the Pillow calls written out."""
+    from PIL import Image
+    rng = np.random.RandomState(0)
+    pil = Image.fromarray(rng.randint(0, 256, (300, 420, 3), dtype=np.uint8), "RGB")
+    aug = {"scale": (0.4, 1.0), "color_jitter": (0.32, 0.32, 0.32, 0.08), "color_jitter_prob": 0.8, "gray_scale_prob": 0.2}
+    m, tr, va = clipa_amd.create_model_and_transforms("ViT-S-16", force_image_size=112, aug_cfg=aug, to_float_on_device=True)
+    assert m.visual.image_size == (112, 112)
+    torch.manual_seed(3)
+    import random
+    random.seed(3)
+    a = tr(pil)
+    assert a.dtype == torch.uint8 and tuple(a.shape) == (3, 112, 112)
+    torch.manual_seed(3)
+    random.seed(3)
+    assert torch.equal(a, tr(pil))                                   # driven by the torch / python RNGs, as torchvision's are
+    v = va(pil)
+    assert v.dtype == torch.uint8 and tuple(v.shape) == (3, 112, 112)
+    # Resize(112) = shorter edge to 112 (bicubic), long edge int(112 * 420 / 300) = 156; CenterCrop(112)
+    ref = pil.resize((156, 112), Image.BICUBIC)
+    left = int(round((156 - 112) / 2.0))
+    ref = np.array(ref.crop((left, 0, left + 112, 112)))
+    assert np.array_equal(v.permute(1, 2, 0).numpy(), ref)
+    _, tr_f, va_f = clipa_amd.create_model_and_transforms("ViT-S-16", force_image_size=112)
+    f = va_f(pil)
+    mean = torch.tensor(clipa_amd.OPENAI_DATASET_MEAN).view(3, 1, 1)
+    std = torch.tensor(clipa_amd.OPENAI_DATASET_STD).view(3, 1, 1)
+    assert f.dtype == torch.float32 and torch.allclose(f, (v.float() / 255 - mean) / std, atol=1e-6)
+    assert tuple(tr_f(pil).shape) == (3, 112, 112)
+    # the device pipeline applies the same operations: its CPU oracle is pinned to Pillow by tests/test_augment_cpu.py

@@ -48,10 +48,17 @@ for s in $STAGES; do
       db=$(find gpurun_out/prof -name '*.db' | head -1)
       [ -n "$db" ] && python tools/rocpd_stats.py "$db" > gpurun_out/kernel_stats.csv 2>&1 ;;
     pmcbench)
+      # one bench step per counter set, each in its own rocprofv3 pass (MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE never share a
+      # pass; no tracing domains next to --pmc): traffic, MFMA busy + wait states + effective clock, LDS conflicts, L2 hit rate
       mkdir -p gpurun_out/pmcbench
-      for set in ${PMC_SETS:-FETCH_SIZE WRITE_SIZE}; do
-        (cd /tmp && timeout 400 rocprofv3 --pmc $set -d "$R/gpurun_out/pmcbench/$set" -o pmc -- \
+      declare -A SETS=( [FETCH_SIZE]="FETCH_SIZE" [WRITE_SIZE]="WRITE_SIZE"
+                        [MFMA]="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"
+                        [LDS]="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INST_CYCLES_VMEM"
+                        [L2]="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA_RDREQ_sum TCC_EA_WRREQ_sum TCC_EA_WRREQ_STALL_sum" )
+      for set in ${PMC_SETS:-FETCH_SIZE WRITE_SIZE MFMA LDS L2}; do
+        (cd /tmp && timeout 400 rocprofv3 --pmc ${SETS[$set]} -d "$R/gpurun_out/pmcbench/$set" -o pmc -- \
            python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 --keep-blocks ${PMC_KEEP:-0,0,24,4} > "$R/gpurun_out/pmcbench/$set.log" 2>&1)
+        tail -2 "$R/gpurun_out/pmcbench/$set.log" | cut -c1-300
       done
       python tools/pmc_summary.py gpurun_out/pmcbench gemm attn ln_ > gpurun_out/pmcbench_summary.txt 2>&1 ;;
     *) echo "unknown stage $s" ;;
