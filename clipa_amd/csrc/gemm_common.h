@@ -22,8 +22,6 @@ struct NTArgs {
   int epi, act;
   int abl;   // experiment flags (clipa_internal_debug_set): 1 no global stores, 2 no epilogue, 8 row-major tile order
   int gm;    // A panels per tile group (nt_group_size)
-  unsigned* sync;   // gemm_nta: 8 per-XCD arrival counters (uncached device memory, zeroed per launch) or nullptr
-  int sync_every;   // gemm_nta: the workgroups of an XCD re-align every this many tiles (0 = never)
 };
 
 // Tile order of the persistent NT kernels: an XCD walks groups of `gm` A panels, N-tile major inside a group.  More panels per
@@ -327,7 +325,6 @@ extern std::atomic<int> g_last_gemm;      // clipa_internal_last_gemm: 1 gemm_nt
 constexpr int MAX_DEVICES = 64;
 
 // gemm_nta.hip: the four-wave / hand-scheduled kernel for whole-tile bf16 shapes (clipa_gemm_nt dispatches to it)
-constexpr int NTA_SYNC_EVERY = 0;         // XCD K-phase re-alignment period in tiles (0 = off; experiment flag bits 26..29 override)
 constexpr int NTA_DEFAULT_SCHEDULE = 4;   // profiles/r03_gemm_nta_schedules_0_7_mainloop_ablation.jsonl
 bool nta_eligible(const NTArgs& a, int out_f32);
 int nta_launch(const NTArgs& a, int dev, int num_cu, int sched, hipStream_t st);

@@ -8,7 +8,7 @@ extern "C" {
 #endif
 /* Two relaxed process-global atomics read by the GEMM launchers.  gemm_nt_variant: 0 = per-shape default, 1 keeps whole-tile
  * shapes on gemm_nt2 (and whole-tile fp8 shapes on gemm_nt_f8_kernel), 2 + s selects schedule s of gemm_nta.  flags (wrong
- * results where noted): gemm_nt 2 = main loop only, 8 = row-major tile order, bits 20..25 = tile-group size override, bits 26..29 = XCD re-alignment period of gemm_nta in tiles (15 = off);
+ * results where noted): gemm_nt 2 = main loop only, 8 = row-major tile order, bits 20..25 = tile-group size override;
  * gemm_nta / gemm_f8a 64 = epilogue stores dropped by the bounds check, 128 = every tile stores to tile 0; gemm_tn 1024 /
  * 2048 force the 16x16x32 / ping-pong kernel, 4096 / 8192 force the slice-per-XCD / tile-per-XCD work order, 16384 keeps
  * whole-tile shapes off gemm_tna, 32768 selects its schedule 1, 65536 / 131072 = its operand-fetch ablations. */

@@ -19,6 +19,7 @@ __global__ void patchify_kernel(const void* __restrict__ img, unsigned short* __
                                 float m0, float m1, float m2, float is0, float is1, float is2) {
   const long total = (long)B * g * g * (Kp / 8);
   const int K = 3 * P * P;
+  const bool fast8 = nhwc && (3 * P) % 8 == 0 && (3 * S) % 8 == 0 && ((size_t)img & 7) == 0;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int kc = (int)(idx % (Kp / 8));
     const long patch = idx / (Kp / 8);
@@ -26,6 +27,34 @@ __global__ void patchify_kernel(const void* __restrict__ img, unsigned short* __
     const int py = (int)((patch / g) % g);
     const long b = patch / ((long)g * g);
     float f[8];
+    if (DT == 0 && fast8) {
+      // uint8 NHWC, 3 * P and 3 * S multiples of 8 (16- and 32-pixel patches at the usual image sizes): the 8 elements of this
+      // chunk are 8 CONSECUTIVE BYTES of the image row (a patch row is 3 * P contiguous bytes in (pw, c) order) - one aligned
+      // 8-byte load per thread, consecutive threads read consecutive bytes of the same patch row
+      const int k0 = kc * 8;
+      if (k0 < K) {
+        const int ph = k0 / (3 * P), off = k0 - ph * 3 * P;
+        const size_t src = (((size_t)b * S + (py * P + ph)) * S + px * P) * 3 + off;
+        const uint2 raw = *(const uint2*)((const unsigned char*)img + src);
+        int c = off % 3;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float v = (float)(((i < 4 ? raw.x : raw.y) >> (8 * (i & 3))) & 0xffu);
+          if (normalize) {
+            const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+            const float istd = c == 0 ? is0 : (c == 1 ? is1 : is2);
+            v = (v * (1.0f / 255.0f) - mean) * istd;
+          }
+          f[i] = v;
+          c = c == 2 ? 0 : c + 1;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = 0.f;
+      }
+      *(u32x4*)(out + (size_t)patch * Kp + kc * 8) = pack8(f);
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int k = kc * 8 + i;

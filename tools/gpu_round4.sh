@@ -29,6 +29,8 @@ for s in $STAGES; do
       timeout 600 ./tools/probes/gemm_flag_sweep ${FLAGSWEEP_ARGS:-} > gpurun_out/gemm_flag_sweep.jsonl 2>&1; echo "rc=$?" >> gpurun_out/gemm_flag_sweep.jsonl ;;
     storepol)
       timeout 600 python tools/gemm_lib_ab.py clipa_amd/lib/libclipa_hip.so $(ls clipa_amd/lib/libclipa_var_st*.so) > gpurun_out/store_policy_ab.jsonl 2>&1; echo "rc=$?" >> gpurun_out/store_policy_ab.jsonl ;;
+    libab)
+      timeout 600 python tools/gemm_lib_ab.py clipa_amd/lib/libclipa_hip.so ${LIBAB_LIBS} > gpurun_out/gemm_lib_ab.jsonl 2>&1; echo "rc=$?" >> gpurun_out/gemm_lib_ab.jsonl ;;
     tnab)
       timeout 600 ./tools/probes/gemm_tna_ab ${GEMMAB_ARGS:-} > gpurun_out/gemm_tna_ab.log 2>&1; echo "rc=$?" >> gpurun_out/gemm_tna_ab.log ;;
     fp8conv)
