@@ -560,6 +560,55 @@ extern "C" int clipa_pool_bwd(const float* dout, const int32_t* idx, void* dx, i
   return clipa_check_launch("pool_bwd");
 }
 
+// PatchDropout (open_clip/transformer.py:53-83, applied at :501-502): the kept tokens are a ROW SELECTION of the token matrix.
+// gather: out[r, :] = x[rows[r], :]; scatter (its backward): dx = 0, dx[rows[r], :] = dy[r, :] (the rows are distinct).
+namespace {
+__global__ void gather_rows_kernel(const unsigned short* __restrict__ x, const int64_t* __restrict__ rows,
+                                   unsigned short* __restrict__ out, long n_out, long n_src, int D) {
+  const int dc = D / 8;
+  const long total = n_out * dc;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long r = idx / dc;
+    const int c = (int)(idx - r * dc);
+    const long src = rows[r];
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (src >= 0 && src < n_src) v = *(const u32x4*)(x + (size_t)src * D + c * 8);
+    *(u32x4*)(out + (size_t)r * D + c * 8) = v;
+  }
+}
+__global__ void scatter_rows_kernel(const unsigned short* __restrict__ dy, const int64_t* __restrict__ rows,
+                                    unsigned short* __restrict__ dx, long n_src, long n_dst, int D) {
+  const int dc = D / 8;
+  const long total = n_src * dc;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long r = idx / dc;
+    const int c = (int)(idx - r * dc);
+    const long dst = rows[r];
+    if (dst >= 0 && dst < n_dst) *(u32x4*)(dx + (size_t)dst * D + c * 8) = *(const u32x4*)(dy + (size_t)r * D + c * 8);
+  }
+}
+}  // namespace
+
+extern "C" int clipa_gather_rows(const void* x, const int64_t* rows, void* out, int64_t n_out, int64_t n_src, int64_t D,
+                                 void* stream) {
+  if (D % 8 != 0 || !rows) { clipa_set_error("gather_rows: D%%8 != 0 or no row list"); return CLIPA_ERR_ARG; }
+  if (n_out <= 0) return CLIPA_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n_out * (D / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)x, rows, (unsigned short*)out, (long)n_out, (long)n_src, (int)D);
+  return clipa_check_launch("gather_rows");
+}
+extern "C" int clipa_scatter_rows(const void* dy, const int64_t* rows, void* dx, int64_t n_src, int64_t n_dst, int64_t D,
+                                  void* stream) {
+  if (D % 8 != 0 || !rows) { clipa_set_error("scatter_rows: D%%8 != 0 or no row list"); return CLIPA_ERR_ARG; }
+  if (n_dst <= 0) return CLIPA_OK;
+  const hipError_t e = hipMemsetAsync(dx, 0, (size_t)n_dst * D * 2, (hipStream_t)stream);
+  if (e != hipSuccess) { clipa_set_error("scatter_rows: memset: %s", hipGetErrorString(e)); return CLIPA_ERR_LAUNCH; }
+  if (n_src <= 0) return CLIPA_OK;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for(n_src * (D / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)dy, rows, (unsigned short*)dx, (long)n_src, (long)n_dst, (int)D);
+  return clipa_check_launch("scatter_rows");
+}
+
 extern "C" int clipa_l2norm_fwd(const float* x, float* y, void* y_bf16, float* inv_norm, int64_t rows, int64_t E,
                                 float eps, void* stream) {
   if (rows <= 0) return CLIPA_OK;

@@ -4,6 +4,7 @@ it stands in for (paths relative to /root/reference/clipa_torch):
 
   ResBlockFn     ResidualAttentionBlock.forward            open_clip/transformer.py:238-250
   VisionStemFn   conv1 + cls/pos + ln_pre                  open_clip/transformer.py:480-503
+  TokenDropFn    PatchDropout (row selection)              open_clip/transformer.py:53-83,501-502
   TextStemFn     token_embedding + positional_embedding    open_clip/model.py:245-247
   HeadFn         pool + ln_post/ln_final + projection      transformer.py:509-529, model.py:251-260
   L2NormFn       F.normalize(dim=-1)                       open_clip/model.py:240,263
@@ -299,6 +300,23 @@ class VisionStemFn(torch.autograd.Function):
                 _like_param(dpos, pos) if pos.requires_grad else None,
                 _like_param(d_ln_w, ln_w) if (cfg["ln_pre"] and ln_w.requires_grad) else None,
                 _like_param(d_ln_b, ln_b) if (cfg["ln_pre"] and ln_b.requires_grad) else None)
+
+
+class TokenDropFn(torch.autograd.Function):
+    """PatchDropout (transformer.py:53-83, applied at :501-502): keep the rows `rows` (int64, device) of the [B*L, D] token
+    matrix - the class token of every sample and its randomly kept patches.  Forward = row gather, backward = row scatter
+    into zeros.  (The reference drops BEFORE ln_pre; LayerNorm is per token, so dropping after it selects the same values.)"""
+
+    @staticmethod
+    def forward(ctx, x, rows):
+        ctx.save_for_backward(rows)
+        ctx.n_src = x.shape[0]
+        return ops.gather_rows(x, rows)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (rows,) = ctx.saved_tensors
+        return ops.scatter_rows(dy.contiguous(), rows, ctx.n_src), None
 
 
 class TextStemFn(torch.autograd.Function):

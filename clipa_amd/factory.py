@@ -64,14 +64,15 @@ def create_model(
     model_name = model_name.replace('/', '-')
     if isinstance(device, str):
         device = torch.device(device)
-    if jit or force_custom_text or pretrained_image or (force_patch_dropout or 0) > 0:
-        raise NotImplementedError("clipa_amd.create_model: jit / custom-text / timm-pretrained / patch-dropout "
-                                  "are outside the MI355X hot path")
+    if jit or force_custom_text or pretrained_image:
+        raise NotImplementedError("clipa_amd.create_model: jit / custom-text / timm-pretrained are outside the MI355X hot path")
     model_cfg = configs.get_model_config(model_name)
     if model_cfg is None:
         raise RuntimeError(f'Model config for {model_name} not found; available models {configs.list_models()}.')
     if force_quick_gelu:
         model_cfg["quick_gelu"] = True
+    if force_patch_dropout is not None:
+        model_cfg["vision_cfg"]["patch_dropout"] = force_patch_dropout    # factory.py:182-184
     if force_image_size is not None:
         model_cfg["vision_cfg"]["image_size"] = force_image_size          # factory.py:186-188
     if pos_embed is not None:

@@ -42,6 +42,8 @@ SIGNATURES = {
     "clipa_argmax_tokens": (_I32, [_P, _P, _I64, _I64, _P]),
     "clipa_pool_fwd": (_I32, [_P, _P, _P, _I64, _I64, _I64, _I32, _P]),
     "clipa_pool_bwd": (_I32, [_P, _P, _P, _I64, _I64, _I64, _I32, _P]),
+    "clipa_gather_rows": (_I32, [_P, _P, _P, _I64, _I64, _I64, _P]),
+    "clipa_scatter_rows": (_I32, [_P, _P, _P, _I64, _I64, _I64, _P]),
     "clipa_l2norm_fwd": (_I32, [_P, _P, _P, _P, _I64, _I64, _F, _P]),
     "clipa_l2norm_bwd": (_I32, [_P, _P, _P, _P, _I64, _I64, _P]),
     "clipa_colsum_workspace": (_I64, [_I64, _I64]),

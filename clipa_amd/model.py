@@ -176,12 +176,23 @@ class Transformer(nn.Module):
         return tokens * 5 * self.width * 2 + tokens * self.heads * 8   # qkv, a, x1 (bf16) + softmax stats
 
 
+def patch_dropout_indices(batch, num_tokens, prob):
+    """open_clip/transformer.py:76-81: the kept patch indices of PatchDropout, drawn exactly as the reference draws them
+    (`torch.randn(batch, num_tokens)` from the global CPU generator, top-k of the noise) -> int64 [batch, num_keep]."""
+    num_keep = max(1, int(num_tokens * (1 - prob)))
+    rand = torch.randn(batch, num_tokens)
+    return rand.topk(num_keep, dim=-1).indices
+
+
 class VisionTransformer(nn.Module):
     """transformer.py:329-534 (patch-embed ViT, cls/GAP pooling, ln_post, proj)."""
 
     def __init__(self, image_size, patch_size, width, layers, heads, mlp_ratio, output_dim, global_average_pool=False,
-                 act=ops.ACT_GELU_ERF, pos_embed='learnable', ln_pre=True, pool_style='open_clip', cache=None):
+                 act=ops.ACT_GELU_ERF, pos_embed='learnable', ln_pre=True, pool_style='open_clip', cache=None,
+                 patch_dropout=0.):
         super().__init__()
+        assert 0 <= patch_dropout < 1.
+        self.patch_dropout = float(patch_dropout)      # transformer.py:386-388 (0 = disabled)
         image_size = image_size if isinstance(image_size, (tuple, list)) else (image_size, image_size)
         patch_size = patch_size if isinstance(patch_size, (tuple, list)) else (patch_size, patch_size)
         if image_size[0] != image_size[1] or patch_size[0] != patch_size[1]:
@@ -261,6 +272,13 @@ class VisionTransformer(nn.Module):
         ln_b = self.ln_pre.bias if has_ln_pre else self.class_embedding
         x0 = engine.VisionStemFn.apply(x, cfg, self._cache, self.conv1.weight, self.class_embedding,
                                        self.positional_embedding, ln_w, ln_b)
+        if self.training and self.patch_dropout > 0.:
+            # transformer.py:501-502: PatchDropout between the positional embedding and ln_pre; LayerNorm is per token, so the
+            # row selection is applied to the stem's output.  The rest of the tower runs on 1 + kept tokens per sample.
+            keep = patch_dropout_indices(B, L - 1, self.patch_dropout)                    # [B, K] patch indices, CPU
+            rows = torch.cat([torch.zeros(B, 1, dtype=torch.int64), keep + 1], dim=1) + torch.arange(B).view(B, 1) * L
+            x0 = engine.TokenDropFn.apply(x0, rows.reshape(-1).to(x0.device, non_blocking=True))
+            L = 1 + keep.shape[1]
         xL = self.transformer.run(x0, B, L, False, self._cache)
         hcfg = {"B": B, "L": L, "mode": self._pool_mode(), "eps": 1e-5}
         return engine.HeadFn.apply(xL, None, hcfg, self._cache, self.ln_post.weight, self.ln_post.bias, self.proj)
@@ -278,9 +296,9 @@ class CLIP(nn.Module):
             text_cfg = CLIPTextCfg(**text_cfg)
         if vision_cfg.timm_model_name or isinstance(vision_cfg.layers, (tuple, list)):
             _unsupported("timm / ResNet vision towers")
-        if vision_cfg.attentional_pool or vision_cfg.input_patchnorm or vision_cfg.patch_dropout > 0 or \
+        if vision_cfg.attentional_pool or vision_cfg.input_patchnorm or \
                 vision_cfg.ls_init_value is not None or text_cfg.ls_init_value is not None:
-            _unsupported("attentional pool / patchnorm / patch dropout / layer scale")
+            _unsupported("attentional pool / patchnorm / layer scale")
         if text_cfg.hf_model_name or text_cfg.embed_cls:
             _unsupported("HF text towers / embed_cls")
         self._cache = engine.WeightCache()
@@ -290,7 +308,8 @@ class CLIP(nn.Module):
             layers=vision_cfg.layers, heads=vision_cfg.width // vision_cfg.head_width, mlp_ratio=vision_cfg.mlp_ratio,
             output_dim=embed_dim, global_average_pool=vision_cfg.global_average_pool,
             act=_act_code(quick_gelu, vision_cfg.gelu_approximate), pos_embed=vision_cfg.pos_embed,
-            ln_pre=vision_cfg.ln_pre, pool_style=vision_cfg.pool_style, cache=self._cache)
+            ln_pre=vision_cfg.ln_pre, pool_style=vision_cfg.pool_style, cache=self._cache,
+            patch_dropout=vision_cfg.patch_dropout)
         # text tower: sub-modules live directly on CLIP (model.py:216-225)
         self.transformer = Transformer(text_cfg.width, text_cfg.layers, text_cfg.heads,
                                        act=_act_code(quick_gelu, text_cfg.gelu_approximate))

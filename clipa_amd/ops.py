@@ -466,6 +466,28 @@ def pool_bwd(dout, B, L, mode, idx=None):
     return dx
 
 
+def gather_rows(x, rows):
+    """out[r] = x[rows[r]]: bf16 [n_src, D], int64 device row list -> bf16 [len(rows), D] (PatchDropout's token selection)."""
+    _chk(x, bf16, "x", 2)
+    _chk(rows, torch.int64, "rows", 1)
+    x = x.contiguous()
+    out = torch.empty((rows.numel(), x.shape[1]), device=x.device, dtype=bf16)
+    with _Timed("gather_rows", 0.0, 4.0 * out.numel()):
+        lib.call("clipa_gather_rows", _p(x), _p(rows), _p(out), rows.numel(), x.shape[0], x.shape[1], _stream())
+    return out
+
+
+def scatter_rows(dy, rows, n_dst):
+    """dx [n_dst, D] = 0; dx[rows[r]] = dy[r] (distinct rows): the backward of gather_rows."""
+    _chk(dy, bf16, "dy", 2)
+    _chk(rows, torch.int64, "rows", 1)
+    dy = dy.contiguous()
+    dx = torch.empty((n_dst, dy.shape[1]), device=dy.device, dtype=bf16)
+    with _Timed("scatter_rows", 0.0, 2.0 * (dx.numel() + 2 * dy.numel())):
+        lib.call("clipa_scatter_rows", _p(dy), _p(rows), _p(dx), dy.shape[0], n_dst, dy.shape[1], _stream())
+    return dx
+
+
 def l2norm_fwd(x, eps=1e-12, want_bf16=False):
     x = x.contiguous()
     rows, E = x.shape

@@ -141,6 +141,13 @@ int clipa_pool_fwd(const void* x, const int32_t* idx, float* out, int64_t B, int
                    void* stream);
 int clipa_pool_bwd(const float* dout, const int32_t* idx, void* dx, int64_t B, int64_t L, int64_t D,
                    int mode, void* stream);
+/* PatchDropout (transformer.py:53-83,501-502): the kept tokens as a row selection of the bf16 token matrix.
+ * gather: out[r,:] = x[rows[r],:] (r < n_out; rows outside [0, n_src) read zeros); scatter = its backward:
+ * dx[n_dst, D] = 0, dx[rows[r],:] = dy[r,:] (rows distinct).  rows: int64 on the device.  D % 8 == 0. */
+int clipa_gather_rows(const void* x, const int64_t* rows, void* out, int64_t n_out, int64_t n_src, int64_t D,
+                      void* stream);
+int clipa_scatter_rows(const void* dy, const int64_t* rows, void* dx, int64_t n_src, int64_t n_dst, int64_t D,
+                       void* stream);
 /* F.normalize(x, dim=-1) (model.py:240,263); y_bf16 optional second output */
 int clipa_l2norm_fwd(const float* x, float* y, void* y_bf16, float* inv_norm, int64_t rows, int64_t E,
                      float eps, void* stream);

@@ -105,8 +105,9 @@ def normalize_images(images_u8, mean=OPENAI_DATASET_MEAN, std=OPENAI_DATASET_STD
     return (x - m) / s
 
 
-def encode_image(sd, cfg, image, emulate_bf16=False):
-    """image [B,3,S,S] float (already normalised) -> un-normalised features [B,E]."""
+def encode_image(sd, cfg, image, emulate_bf16=False, patch_keep=None):
+    """image [B,3,S,S] float (already normalised) -> un-normalised features [B,E].  patch_keep: int64 [B, K] kept patch
+    indices of PatchDropout in training mode (transformer.py:53-83, applied at :501-502) or None."""
     e = emulate_bf16
     v = cfg["vision"]
     P, D, H = v["patch_size"], v["width"], v["heads"]
@@ -118,6 +119,10 @@ def encode_image(sd, cfg, image, emulate_bf16=False):
     cls = _q(sd["visual.class_embedding"], e).expand(B, 1, D)
     x = torch.cat([cls, x], dim=1)
     x = _q(x + _q(sd["visual.positional_embedding"], e), e)
+    if patch_keep is not None:       # transformer.py:67-83: the class token is excluded from the draw and put back in front
+        cls_tokens, xp = x[:, :1], x[:, 1:]
+        xp = xp[torch.arange(B)[..., None], patch_keep]
+        x = torch.cat((cls_tokens, xp), dim=1)
     if v.get("ln_pre", True):
         x = _q(layer_norm(x, sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"]), e)
     for i in range(_n_layers(sd, "visual.transformer.")):
@@ -155,8 +160,8 @@ def l2_normalize(x, eps=1e-12):
     return x / x.norm(dim=-1, keepdim=True).clamp_min(eps)
 
 
-def clip_forward(sd, cfg, image, text, emulate_bf16=False):
-    i = l2_normalize(encode_image(sd, cfg, image, emulate_bf16))
+def clip_forward(sd, cfg, image, text, emulate_bf16=False, patch_keep=None):
+    i = l2_normalize(encode_image(sd, cfg, image, emulate_bf16, patch_keep))
     t = l2_normalize(encode_text(sd, cfg, text, emulate_bf16))
     return i, t, sd["logit_scale"].exp()
 

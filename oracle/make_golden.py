@@ -50,7 +50,17 @@ CASES = {
         "embed_dim": 64,
         "vision_cfg": {"image_size": 42, "layers": 2, "width": 160, "head_width": 80, "patch_size": 14},
         "text_cfg": {"context_length": 16, "vocab_size": 512, "width": 128, "heads": 2, "layers": 2}}),
+    # PatchDropout (transformer.py:53-83; the reference's ViT-H/14 fine-tune scripts pass --force-patch-dropout): training
+    # mode, 16 patches of which 8 are kept per sample (drawn from the global CPU generator after manual_seed(drop_seed)),
+    # GAP pooling over the kept tokens
+    "patchdrop_gap": dict(B=8, S=64, seed=15, drop_seed=1234, cfg={
+        "embed_dim": 64,
+        "vision_cfg": {"image_size": 64, "layers": 2, "width": 128, "patch_size": 16, "global_average_pool": True,
+                       "patch_dropout": 0.5},
+        "text_cfg": {"context_length": 16, "vocab_size": 512, "width": 128, "heads": 2, "layers": 2}}),
 }
+# fixtures whose forward is stochastic in training mode: not part of the generic MODEL_CASES sweeps of the test-suite
+STOCHASTIC_CASES = ("patchdrop_gap",)
 
 
 # Full model dimensions (SURVEY 8c "planned oracle artefacts"): the reference's own model_configs/*.json at BASELINE
@@ -103,6 +113,16 @@ def run_case(name, spec, ref_model, ref_loss):
     model.load_state_dict(sd, strict=True)
     images_u8, texts = O.synthetic_batch(B, S, cfg["text_cfg"]["context_length"], cfg["text_cfg"]["vocab_size"], seed)
     images = O.normalize_images(images_u8)          # train.py:191-197
+    extra = {}
+    if "drop_seed" in spec:
+        # the first random draw of a training-mode forward is PatchDropout's torch.randn(batch, num_tokens) (transformer.py:79):
+        # the same seed reproduces the kept indices for the fixture
+        model.train()
+        n_tok = (S // cfg["vision_cfg"]["patch_size"]) ** 2
+        torch.manual_seed(spec["drop_seed"])
+        keep = torch.randn(B, n_tok).topk(max(1, int(n_tok * (1 - cfg["vision_cfg"]["patch_dropout"]))), dim=-1).indices
+        extra = {"patch_keep": keep.numpy(), "drop_seed": spec["drop_seed"]}
+        torch.manual_seed(spec["drop_seed"])
     out = model(images, texts)
     loss_fn = ref_loss.ClipLoss(local_loss=False, gather_with_grad=False, cache_labels=True, rank=0, world_size=1)
     logits_i, _ = loss_fn.get_logits(out["image_features"], out["text_features"], out["logit_scale"])
@@ -119,7 +139,7 @@ def run_case(name, spec, ref_model, ref_loss):
         image_features=out["image_features"].detach().numpy(), text_features=out["text_features"].detach().numpy(),
         logit_scale=out["logit_scale"].detach().numpy(), logits_per_image=logits_i.detach().numpy(),
         loss=loss.detach().numpy(), grad_names=np.array(names), grad_norms=norms, grad_sums=sums,
-        grad_sample_idx=idxs, grad_sample_vals=vals)
+        grad_sample_idx=idxs, grad_sample_vals=vals, **extra)
     print(f"{name}: loss={float(loss):.7f} params={len(shapes)} grads={len(names)}")
 
 

@@ -263,3 +263,13 @@ def reduce_shards(pieces, world, out=None, scale=None, out_dtype=None):
         return r.to(out_dtype or pieces.dtype)
     out.copy_(r)
     return out
+
+
+def gather_rows(x, rows):
+    return x[rows].contiguous()
+
+
+def scatter_rows(dy, rows, n_dst):
+    dx = torch.zeros((n_dst, dy.shape[1]), dtype=dy.dtype)
+    dx[rows] = dy
+    return dx

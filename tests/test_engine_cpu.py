@@ -63,6 +63,47 @@ def test_engine_orchestration_matches_reference_golden(golden):
         assert abs(float(a.norm() / b.norm()) - 1) < 0.05, n
 
 
+def _patch_dropout_check(dev_move=None):
+    """Shared by the CPU (stand-in ops) and GPU tests: the engine in training mode with the fixture's seed draws the
+    reference's kept indices, and features / loss / every gradient follow the real reference's training-mode forward."""
+    g = load_golden("patchdrop_gap")
+    m = clipa_amd.CLIP(**g.cfg, output_dict=True)
+    m.load_state_dict(g.sd, strict=True)
+    if dev_move is not None:
+        m = dev_move(m)
+    m.set_grad_checkpointing(True)
+    m.visual.transformer.keep_blocks, m.visual.transformer.medium_blocks = 0, 1
+    images, texts = (g.images_u8, g.texts) if dev_move is None else (dev_move(g.images_u8), dev_move(g.texts))
+    assert m.training and m.visual.patch_dropout == 0.5
+    torch.manual_seed(g.drop_seed)
+    out = m(images, texts)
+    loss = clipa_amd.ClipLoss()(**out, output_dict=True)["contrastive_loss"]
+    loss.backward()
+    assert (out["image_features"].float().cpu() - g.t("image_features")).abs().max() < 2e-2
+    assert abs(float(loss) - float(g.t("loss"))) < 2e-2 * float(g.t("loss"))
+    sd = {k: v.clone().requires_grad_(k not in g.frozen) for k, v in g.sd.items()}
+    i, t, s = O.clip_forward(sd, g.ocfg, O.normalize_images(g.images_u8), g.texts, patch_keep=g.patch_keep)
+    O.clip_loss(i, t, s)[0].backward()
+    got = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    assert sorted(got) == sorted(str(n) for n in g.z["grad_names"])
+    for n, p in got.items():
+        a, b = p.double().cpu().reshape(-1), sd[n].grad.double().reshape(-1)
+        if float(b.norm()) < 1e-7 or a.numel() == 1:
+            continue
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+        assert cos > 0.99 and abs(float(a.norm() / b.norm()) - 1) < 0.05, (n, cos)
+    # eval mode: no dropout, every patch token is used
+    m.eval()
+    with torch.no_grad():
+        e = m(images, texts)
+    i0, _, _ = O.clip_forward(g.sd, g.ocfg, O.normalize_images(g.images_u8), g.texts)
+    assert (e["image_features"].float().cpu() - i0).abs().max() < 2e-2
+
+
+def test_patch_dropout_orchestration_matches_reference_golden():
+    _patch_dropout_check()
+
+
 def test_recompute_equals_stored(golden):
     ma, _, la = _run(golden, recompute=True)
     mb, _, lb = _run(golden, recompute=False)

@@ -256,6 +256,15 @@ def test_two_resolution_handoff_matches_reference_and_trains(tmp_path):
     assert all(math.isfinite(v) for v in l224) and l224[-1] < l224[0], l224
 
 
+def test_patch_dropout_matches_reference_golden():
+    """PatchDropout (transformer.py:53-83,501-502; `--force-patch-dropout` of the reference's ViT-H/14 fine-tune recipes) on
+    the HIP engine: row-gather / row-scatter kernels around the tower, against the real reference's training-mode forward
+    (tests/golden/patchdrop_gap.npz) and the oracle's gradients with the same kept indices."""
+    from .test_engine_cpu import _patch_dropout_check
+    _patch_dropout_check(lambda t: t.to(DEV))
+    torch.cuda.synchronize()
+
+
 def test_recompute_equals_stored_activations(golden):
     g = golden
     ga = {}

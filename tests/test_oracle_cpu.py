@@ -47,6 +47,38 @@ def _check_oracle_against_golden(g, feat_atol=3e-6, logit_atol=5e-5, loss_atol=1
         assert np.allclose(gr[idx].numpy(), g.z["grad_sample_vals"][j], atol=2e-4 * ref_norm + 1e-7), n
 
 
+def test_oracle_patch_dropout_matches_reference_golden():
+    """PatchDropout (transformer.py:53-83, applied at :501-502) in training mode: the oracle with the reference's kept indices
+    reproduces the real reference's features, logits, loss and every gradient digest; and the engine-side index draw
+    (clipa_amd.model.patch_dropout_indices: torch.randn from the global CPU generator + top-k, as transformer.py:79-80)
+    reproduces those indices from the fixture's seed."""
+    from .conftest import load_golden
+    import clipa_amd.model as M
+    g = load_golden("patchdrop_gap")
+    assert g.patch_keep is not None and tuple(g.patch_keep.shape) == (8, 8)
+    torch.manual_seed(g.drop_seed)
+    assert torch.equal(M.patch_dropout_indices(8, 16, 0.5), g.patch_keep)
+    sd = {k: v.clone().requires_grad_(k not in g.frozen) for k, v in g.sd.items()}
+    i, t, s = O.clip_forward(sd, g.ocfg, O.normalize_images(g.images_u8), g.texts, patch_keep=g.patch_keep)
+    loss, logits = O.clip_loss(i, t, s)
+    loss.backward()
+    assert torch.allclose(i, g.t("image_features"), atol=3e-6, rtol=1e-5)
+    assert torch.allclose(logits, g.t("logits_per_image"), atol=5e-5, rtol=1e-5)
+    assert abs(float(loss) - float(g.t("loss"))) < 1e-5
+    names = [str(n) for n in g.z["grad_names"]]
+    grads = {k: v.grad for k, v in sd.items() if v.grad is not None}
+    assert sorted(grads) == names
+    for j, n in enumerate(names):
+        gr = grads[n].double().reshape(-1)
+        ref_norm = float(g.z["grad_norms"][j])
+        assert abs(float(gr.norm()) - ref_norm) <= 2e-4 * ref_norm + 1e-7, n
+        idx = torch.from_numpy(g.z["grad_sample_idx"][j])
+        assert np.allclose(gr[idx].numpy(), g.z["grad_sample_vals"][j], atol=2e-4 * ref_norm + 1e-7), n
+    # without the indices (eval mode) the oracle is the plain forward: different features
+    i0, _, _ = O.clip_forward(g.sd, g.ocfg, O.normalize_images(g.images_u8), g.texts)
+    assert (i0 - g.t("image_features")).abs().max() > 1e-3
+
+
 def test_oracle_fp64_agrees_with_fp32(golden):
     i32, t32, _, l32, _, _ = _oracle_run(golden, torch.float32)
     i64, t64, _, l64, _, _ = _oracle_run(golden, torch.float64)
