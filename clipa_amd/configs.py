@@ -43,6 +43,15 @@ def _builtin():
     cfgs["ViT-L-16-CL32-GAP"] = _vit("L", 16, ctx=32, gap=True)
     cfgs["ViT-H-14-CL8-SyntaxMask-GAP"] = _vit("H", 14, ctx=8, gap=True, text_mask="syntax")
     cfgs["ViT-H-14-CL32-GAP"] = _vit("H", 14, ctx=32, gap=True)
+    # the reference's largest towers (model_configs/ViT-g-14.json, ViT-bigG-14.json - CLIPA-v2's G/14 -, ViT-e-14.json):
+    # head widths 88 / 104 / 112, fractional mlp_ratio (MLP widths 6144 / 8192 / 15360)
+    for name, (e, w, layers, hw, mlp, tw, th, tl) in {
+            "ViT-g-14": (1024, 1408, 40, 88, 4.3637, 1024, 16, 24), "ViT-bigG-14": (1280, 1664, 48, 104, 4.9231, 1280, 20, 32),
+            "ViT-e-14": (1280, 1792, 56, 112, 8.5715, 1280, 20, 36)}.items():
+        cfgs[name] = {"embed_dim": e,
+                      "vision_cfg": {"image_size": 224, "layers": layers, "width": w, "head_width": hw, "mlp_ratio": mlp,
+                                     "patch_size": 14},
+                      "text_cfg": {"context_length": 77, "vocab_size": 49408, "width": tw, "heads": th, "layers": tl}}
     return cfgs
 
 

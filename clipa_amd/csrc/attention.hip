@@ -1,5 +1,6 @@
 // Fused multi-head self-attention forward / backward for short sequences (L <= 288 in one piece, 288 < L <= 1024
-// streamed in 256-row chunks; head dim 64 or 80)
+// streamed in 256-row chunks; head dim 64 or 80, and - compiled by attention_wide.hip from this
+// same source - the wide heads 88 / 104 / 112 of ViT-g/14, ViT-bigG/14, ViT-e/14)
 // on gfx950.  Replaces torch scaled_dot_product_attention as called from nn.MultiheadAttention in
 // clipa_torch/open_clip/transformer.py:209,223-236 (softmax(q.k^T/sqrt(dh) + mask).v, dropout 0;
 // mask = None for the image tower, additive causal triu(1)*-inf for text, transformer.py:618-624).
@@ -40,7 +41,7 @@ template <int DH>
 struct HD {
   static constexpr int RB = DH == 64 ? 128 : 256;   // LDS row bytes
   static constexpr int NCH = RB / 16;               // 16-byte chunk positions per row
-  static constexpr int KS = DH / 16;                // 16-wide reduction steps over the head dim
+  static constexpr int KS = (DH + 15) / 16;         // 16-wide reduction steps over the head dim (a ragged last step sees zeros)
   static constexpr int DT = (DH + 31) / 32;         // 32-wide output tiles over the head dim
   static constexpr int WGS = DH == 64 ? 2 : 1;      // workgroups per CU the LDS image allows
 };
@@ -55,7 +56,7 @@ struct WGHeads {
 // CU; four waves there leave every SIMD a single wave and nothing to overlap its MFMA -> softmax -> MFMA chain with, so those
 // instantiations run eight waves (two per SIMD, one 32-row tile each for all but one wave).
 template <int NKT, int DH>
-__host__ __device__ constexpr int attn_waves() { return (DH == 80 && NKT >= 5) ? 8 : 4; }
+__host__ __device__ constexpr int attn_waves() { return (DH == 80 && NKT >= 5) ? 8 : 4; }   // (wider heads spill at 256 registers per wave)
 
 // chunk permutation of an LDS row: conflict-free for both the direct ds_read_b128 operand reads and the
 // transposed ds_read_b64_tr_b16 reads (tools/lds_bank_sim.py) - 8 chunks per 128-B row, 16 per 256-B row
@@ -236,21 +237,25 @@ __device__ __forceinline__ void softmax_rows(f32x16 (&s)[NKT], const AttnArgs& p
 }
 
 // load the k-step fragments of one 32-row tile straight from global memory (rows >= L read zeros)
-template <int KS>
+// (chunks at or beyond the head dim - the ragged last k-step of head dims 88 / 104 - would be the NEXT head's columns: their
+// offset is pushed out of the descriptor's range, which returns zeros, as dma_image does for the LDS images)
+template <int KS, int DH>
 __device__ __forceinline__ void load_frags(const __amdgpu_buffer_rsrc_t rs, long ld, int row, int hi, bf16x8 (&f)[KS]) {
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
-    f[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(row * ld * 2 + (2 * ks + hi) * 16), 0, 0));
+  for (int ks = 0; ks < KS; ++ks) {
+    const unsigned oob = ((2 * ks + hi) * 8 >= DH) ? 0x80000000u : 0u;
+    f[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(row * ld * 2 + (2 * ks + hi) * 16) | oob, 0, 0));
+  }
 }
 
 // whole-row stores (store_tile) need 16 / 10 KB of LDS more per workgroup: taken where the workgroups per CU stay what they are
 template <int NKT, int DH>
 __host__ __device__ constexpr bool fwd_stages() {
-  return (WGHeads<NKT>::HPW * 2 * NKT * 32 * HD<DH>::RB + attn_waves<NKT, DH>() * Stg<DH>::BYTES) * HD<DH>::WGS <= 160 * 1024;
+  return (DH == 64 || DH == 80) && (WGHeads<NKT>::HPW * 2 * NKT * 32 * HD<DH>::RB + attn_waves<NKT, DH>() * Stg<DH>::BYTES) * HD<DH>::WGS <= 160 * 1024;
 }
 template <int NKT, int DH>
 __host__ __device__ constexpr bool bwd_stages() {
-  return (WGHeads<NKT>::HPW * (2 * NKT * 32 * HD<DH>::RB + 3 * NKT * 32 * 4) + attn_waves<NKT, DH>() * Stg<DH>::BYTES) * HD<DH>::WGS <= 160 * 1024;
+  return (DH == 64 || DH == 80) && (WGHeads<NKT>::HPW * (2 * NKT * 32 * HD<DH>::RB + 3 * NKT * 32 * 4) + attn_waves<NKT, DH>() * Stg<DH>::BYTES) * HD<DH>::WGS <= 160 * 1024;
 }
 
 template <int NKT, int DH, bool CAUSAL>
@@ -284,7 +289,7 @@ __global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void att
   // tiles at head dim 64 - keeps the plain load)
   constexpr bool PREFETCH = !(NKT == 9 && DH == 64);
   bf16x8 fq[KS], fqn[KS];
-  if (PREFETCH) load_frags<KS>(rsQ, p.ld_qkv, 32 * wave + l31, hi, fqn);
+  if (PREFETCH) load_frags<KS, DH>(rsQ, p.ld_qkv, 32 * wave + l31, hi, fqn);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -293,9 +298,9 @@ __global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void att
     if (PREFETCH) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) fq[ks] = fqn[ks];
-      if (qt + WPH < NKT) load_frags<KS>(rsQ, p.ld_qkv, qg + 32 * WPH, hi, fqn);
+      if (qt + WPH < NKT) load_frags<KS, DH>(rsQ, p.ld_qkv, qg + 32 * WPH, hi, fqn);
     } else {
-      load_frags<KS>(rsQ, p.ld_qkv, qg, hi, fq);
+      load_frags<KS, DH>(rsQ, p.ld_qkv, qg, hi, fq);
     }
     f32x16 s[NKT];
 #pragma unroll
@@ -389,17 +394,17 @@ __global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void att
   dma_image<DH>(rsK, img0, LP, p.ld_qkv, wave, lane, WPH);
   dma_image<DH>(rsV, img1, LP, p.ld_qkv, wave, lane, WPH);
   bf16x8 fq[KS], fdo[KS], fo[KS];
-  load_frags<KS>(rsQ, p.ld_qkv, 32 * wave + l31, hi, fq);        // first tile's rows ride along with the DMA
-  load_frags<KS>(rsDO, p.ld_o, 32 * wave + l31, hi, fdo);
-  load_frags<KS>(rsO, p.ld_o, 32 * wave + l31, hi, fo);
+  load_frags<KS, DH>(rsQ, p.ld_qkv, 32 * wave + l31, hi, fq);        // first tile's rows ride along with the DMA
+  load_frags<KS, DH>(rsDO, p.ld_o, 32 * wave + l31, hi, fdo);
+  load_frags<KS, DH>(rsO, p.ld_o, 32 * wave + l31, hi, fo);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int qt = wave; qt < NKT; qt += WPH) {
     const int qg = 32 * qt + l31;
     if (qt != wave) {
-      load_frags<KS>(rsQ, p.ld_qkv, qg, hi, fq);
-      load_frags<KS>(rsDO, p.ld_o, qg, hi, fdo);
-      load_frags<KS>(rsO, p.ld_o, qg, hi, fo);
+      load_frags<KS, DH>(rsQ, p.ld_qkv, qg, hi, fq);
+      load_frags<KS, DH>(rsDO, p.ld_o, qg, hi, fdo);
+      load_frags<KS, DH>(rsO, p.ld_o, qg, hi, fo);
     }
     float2 st = make_float2(0.f, 0.f);                 // padded queries: inv = 0 -> P = 0
     if (qg < p.L) st = *(const float2*)(stats + qg * 2);
@@ -478,8 +483,8 @@ __global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void att
     const int kg = 32 * kt + l31;
     const int kgc = l31 - 4 * hi;      // causal test inside the diagonal tile: key <= query
     if (kt != wave) {
-      load_frags<KS>(rsK, p.ld_qkv, kg, hi, fk);
-      load_frags<KS>(rsV, p.ld_qkv, kg, hi, fv);
+      load_frags<KS, DH>(rsK, p.ld_qkv, kg, hi, fk);
+      load_frags<KS, DH>(rsV, p.ld_qkv, kg, hi, fv);
     }
     f32x16 dk[DT], dv[DT];
 #pragma unroll
@@ -583,7 +588,7 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_fwd_long_kernel(AttnArg
     const int qt = qt0 + wave;
     const int qg = 32 * qt + l31;                        // rows >= L read zeros and are never stored
     bf16x8 fq[KS];
-    load_frags<KS>(rsQ, p.ld_qkv, qg, hi, fq);
+    load_frags<KS, DH>(rsQ, p.ld_qkv, qg, hi, fq);
     const int lim2 = (CAUSAL ? min(p.L, qg + 1) : p.L) - 4 * hi;
     float m_run = -1e30f, l_run = 0.f;
     f32x16 o[DT];
@@ -695,9 +700,9 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_long_kernel(AttnArg
     const int qt = qt0 + wave;
     const int qg = 32 * qt + l31;
     bf16x8 fq[KS], fdo[KS], fo[KS];
-    load_frags<KS>(rsQ, p.ld_qkv, qg, hi, fq);
-    load_frags<KS>(rsDO, p.ld_o, qg, hi, fdo);
-    load_frags<KS>(rsO, p.ld_o, qg, hi, fo);
+    load_frags<KS, DH>(rsQ, p.ld_qkv, qg, hi, fq);
+    load_frags<KS, DH>(rsDO, p.ld_o, qg, hi, fdo);
+    load_frags<KS, DH>(rsO, p.ld_o, qg, hi, fo);
     float2 st = make_float2(0.f, 0.f);                 // padded queries: inv = 0 -> P = 0
     if (qg < p.L) st = *(const float2*)(stats + qg * 2);
     float Dq = 0.f;
@@ -766,8 +771,8 @@ __global__ __launch_bounds__(256, HD<DH>::WGS) void attn_bwd_long_kernel(AttnArg
     const int kg = 32 * kt + l31;
     const int kgc = l31 - 4 * hi;      // causal test inside the diagonal tile: key <= query
     bf16x8 fk[KS], fv[KS];
-    load_frags<KS>(rsK, p.ld_qkv, kg, hi, fk);
-    load_frags<KS>(rsV, p.ld_qkv, kg, hi, fv);
+    load_frags<KS, DH>(rsK, p.ld_qkv, kg, hi, fk);
+    load_frags<KS, DH>(rsV, p.ld_qkv, kg, hi, fv);
     f32x16 dk[DT], dv[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -901,14 +906,19 @@ int launch_long(const AttnArgs& a, hipStream_t st) {
   else hipLaunchKernelGGL((attn_fwd_long_kernel<DH, CAUSAL>), grid, dim3(256), lds, st, a);
   return clipa_check_launch(BWD ? "attn_bwd_long" : "attn_fwd_long");
 }
+#ifndef CLIPA_ATTN_WIDE
 template <bool BWD>
 int dispatch_long(const AttnArgs& a, int64_t dh, hipStream_t st) {
   if (dh == 80) return a.causal ? launch_long<80, true, BWD>(a, st) : launch_long<80, false, BWD>(a, st);
   return a.causal ? launch_long<64, true, BWD>(a, st) : launch_long<64, false, BWD>(a, st);
 }
+#endif
 
-int check_args(int64_t B, int64_t H, int64_t L, int64_t dh, int64_t ld_qkv, int64_t ld_o) {
-  if (dh != 64 && dh != 80) { clipa_set_error("attention: head dim %ld unsupported (64 and 80 only)", (long)dh); return CLIPA_ERR_ARG; }
+bool wide_head(int64_t dh) { return dh == 88 || dh == 104 || dh == 112; }
+
+int check_args(int64_t B, int64_t H, int64_t L, int64_t dh, int64_t ld_qkv, int64_t ld_o, int causal) {
+  if (dh != 64 && dh != 80 && !wide_head(dh)) { clipa_set_error("attention: head dim %ld unsupported (64, 80, 88, 104, 112)", (long)dh); return CLIPA_ERR_ARG; }
+  if (wide_head(dh) && causal) { clipa_set_error("attention: head dim %ld is compiled for image towers only (no causal mask)", (long)dh); return CLIPA_ERR_ARG; }
   if (L <= 0 || L > LONG_LMAX) { clipa_set_error("attention: L=%ld outside (0, %d]", (long)L, LONG_LMAX); return CLIPA_ERR_ARG; }
   if (ld_qkv % 8 != 0 || ld_o % 8 != 0) { clipa_set_error("attention: row strides must be multiples of 8 elements"); return CLIPA_ERR_ARG; }
   if (B * H <= 0 || B * H > 0x7fffffffL) { clipa_set_error("attention: bad B*H"); return CLIPA_ERR_ARG; }
@@ -925,6 +935,26 @@ int check_args(int64_t B, int64_t H, int64_t L, int64_t dh, int64_t ld_qkv, int6
     case 7: return fn<7, DH>(a, st); case 8: return fn<8, DH>(a, st);        \
     default: return fn<9, DH>(a, st);                                        \
   }
+#ifdef CLIPA_ATTN_WIDE
+// attention_wide.hip: the non-causal kernels of the wide heads (ViT-g/14 88, ViT-bigG/14 104, ViT-e/14 112; image towers only),
+// a translation unit of their own so that the build stays parallel.  `args` is this file's AttnArgs.
+template <int NKT, int DH> int wide_fwd(const AttnArgs& a, hipStream_t st) { return launch_fwd_c<NKT, DH, false>(a, st); }
+template <int NKT, int DH> int wide_bwd(const AttnArgs& a, hipStream_t st) { return launch_bwd_c<NKT, DH, false>(a, st); }
+template <int DH>
+int wide_dh(const AttnArgs& a, int bwd, hipStream_t st) {
+  if (a.L > 288) return bwd ? launch_long<DH, false, true>(a, st) : launch_long<DH, false, false>(a, st);
+  if (bwd) { ATTN_DISPATCH_DH(wide_bwd, DH, a, st) }
+  ATTN_DISPATCH_DH(wide_fwd, DH, a, st)
+}
+extern "C" int clipa_attn_wide_launch(const void* args, int64_t dh, int bwd, void* stream) {
+  const AttnArgs& a = *(const AttnArgs*)args;
+  if (dh == 88) return wide_dh<88>(a, bwd, (hipStream_t)stream);
+  if (dh == 104) return wide_dh<104>(a, bwd, (hipStream_t)stream);
+  return wide_dh<112>(a, bwd, (hipStream_t)stream);
+}
+#else
+extern "C" int clipa_attn_wide_launch(const void* args, int64_t dh, int bwd, void* stream);   // attention_wide.hip
+
 #define ATTN_DISPATCH(fn, dh, a, st)                 \
   if ((dh) == 80) { ATTN_DISPATCH_DH(fn, 80, a, st) } \
   ATTN_DISPATCH_DH(fn, 64, a, st)
@@ -933,11 +963,12 @@ extern "C" int clipa_attention_fwd(const void* q, const void* k, const void* v, 
                                    int64_t B, int64_t H, int64_t L, int64_t dh, int64_t ld_qkv, int64_t ld_o,
                                    float scale, int causal, void* stream) {
   if (B * H == 0) return CLIPA_OK;
-  if (int rc = check_args(B, H, L, dh, ld_qkv, ld_o)) return rc;
+  if (int rc = check_args(B, H, L, dh, ld_qkv, ld_o, causal)) return rc;
   AttnArgs a = {};
   a.q = (const char*)q; a.k = (const char*)k; a.v = (const char*)v; a.ld_qkv = ld_qkv;
   a.o = (char*)out; a.ld_o = ld_o; a.B = (int)B; a.H = (int)H; a.L = (int)L; a.scale = scale; a.causal = causal;
   a.stats = stats;
+  if (wide_head(dh)) return clipa_attn_wide_launch(&a, dh, 0, stream);
   if (L > 288) return dispatch_long<false>(a, dh, (hipStream_t)stream);
   ATTN_DISPATCH(launch_fwd, dh, a, (hipStream_t)stream)
 }
@@ -947,7 +978,7 @@ extern "C" int clipa_attention_bwd(const void* q, const void* k, const void* v, 
                                    int64_t L, int64_t dh, int64_t ld_qkv, int64_t ld_o, int64_t ld_dqkv,
                                    float scale, int causal, void* stream) {
   if (B * H == 0) return CLIPA_OK;
-  if (int rc = check_args(B, H, L, dh, ld_qkv, ld_o)) return rc;
+  if (int rc = check_args(B, H, L, dh, ld_qkv, ld_o, causal)) return rc;
   if (ld_dqkv % 8 != 0) { clipa_set_error("attention_bwd: ld_dqkv must be a multiple of 8"); return CLIPA_ERR_ARG; }
   if (!stats) { clipa_set_error("attention_bwd: needs the forward's softmax statistics"); return CLIPA_ERR_ARG; }
   AttnArgs a = {};
@@ -956,6 +987,8 @@ extern "C" int clipa_attention_bwd(const void* q, const void* k, const void* v, 
   a.dq = (char*)dq; a.dk = (char*)dk; a.dv = (char*)dv; a.ld_dqkv = ld_dqkv;
   a.B = (int)B; a.H = (int)H; a.L = (int)L; a.scale = scale; a.causal = causal;
   a.stats = const_cast<float*>(stats);
+  if (wide_head(dh)) return clipa_attn_wide_launch(&a, dh, 1, stream);
   if (L > 288) return dispatch_long<true>(a, dh, (hipStream_t)stream);
   ATTN_DISPATCH(launch_bwd, dh, a, (hipStream_t)stream)
 }
+#endif   // CLIPA_ATTN_WIDE

@@ -138,8 +138,9 @@ class Transformer(nn.Module):
 
     def __init__(self, width, layers, heads, mlp_ratio=4.0, act=ops.ACT_GELU_ERF):
         super().__init__()
-        if width % heads != 0 or width // heads not in (64, 80):
-            _unsupported(f"head dim {width // heads if heads else '?'} (the fused attention kernels cover 64 and 80)")
+        if width % heads != 0 or width // heads not in (64, 80, 88, 104, 112):
+            _unsupported(f"head dim {width // heads if heads else '?'} (the fused attention kernels cover 64, 80 and - image "
+                         f"towers only - 88 / 104 / 112)")
         self.width, self.layers, self.heads, self.act = width, layers, heads, act
         self.grad_checkpointing = False
         # MI355X engine knob (no reference counterpart): with grad checkpointing on, the first `keep_blocks`
@@ -159,6 +160,8 @@ class Transformer(nn.Module):
         return self.resblocks[0].mlp.c_fc.weight.dtype
 
     def run(self, x, B, L, causal, cache):
+        if causal and self.width // self.heads > 80:
+            _unsupported(f"causal attention with head dim {self.width // self.heads} (the wide heads are compiled for image towers)")
         base = {"B": B, "L": L, "H": self.heads, "causal": bool(causal), "act": self.act, "eps": 1e-5,
                 "recompute": bool(self.grad_checkpointing), "keep": "light", "fp8": bool(self.fp8),
                 "fp8_grad_fmt": ops.FMT_E5M2 if self.fp8_grad_format == "e5m2" else ops.FMT_E4M3}

@@ -50,6 +50,12 @@ CASES = {
         "embed_dim": 64,
         "vision_cfg": {"image_size": 42, "layers": 2, "width": 160, "head_width": 80, "patch_size": 14},
         "text_cfg": {"context_length": 16, "vocab_size": 512, "width": 128, "heads": 2, "layers": 2}}),
+    # ViT-g/14 flavour (model_configs/ViT-g-14.json; CLIPA-v2's G/14 is ViT-bigG-14): head_width 88 = 5.5 sixteen-wide
+    # reduction steps, fractional mlp_ratio 4.3637 (176 -> 768), 14 px patches
+    "g14_dh88": dict(B=8, S=42, seed=16, cfg={
+        "embed_dim": 64,
+        "vision_cfg": {"image_size": 42, "layers": 2, "width": 176, "head_width": 88, "mlp_ratio": 4.3637, "patch_size": 14},
+        "text_cfg": {"context_length": 16, "vocab_size": 512, "width": 128, "heads": 2, "layers": 2}}),
     # PatchDropout (transformer.py:53-83; the reference's ViT-H/14 fine-tune scripts pass --force-patch-dropout): training
     # mode, 16 patches of which 8 are kept per sample (drawn from the global CPU generator after manual_seed(drop_seed)),
     # GAP pooling over the kept tokens

@@ -306,6 +306,27 @@ def test_attention(B, H, L, causal, dh):
     check("dqkv", dq.reshape(B, L, 3 * D), x.grad, 2 ** -5, 2e-2)
 
 
+@pytest.mark.parametrize("dh,B,H,L", [(88, 2, 2, 257), (88, 3, 2, 37), (104, 1, 3, 257), (104, 2, 2, 50), (112, 2, 2, 197),
+                                      (112, 1, 2, 26), (88, 1, 2, 577), (104, 1, 1, 300)])
+def test_attention_wide_heads(dh, B, H, L):
+    """Head dims 88 / 104 / 112 (open_clip/model_configs ViT-g-14 / ViT-bigG-14 / ViT-e-14; CLIPA-v2's G/14 tower): 6 - 7
+    k-steps of which the last is ragged for 88 and 104 (zero-filled in the LDS images AND in the fragments read from global
+    memory - a neighbouring head's columns must never leak in: H >= 2 makes that visible), 3 - 4 output tiles with a partial
+    last one; one-piece (L <= 288) and streamed (L = 300, 577) kernels, image towers only (no causal mask)."""
+    D = dh * H
+    qkv = rnd(B * L, 3 * D, seed=230 + L + dh, scale=1.2)
+    dout = rnd(B * L, D, seed=231 + L + dh)
+    x = qkv.double().reshape(B, L, 3 * D).requires_grad_(True)
+    o = O.attention(x, H, False)
+    o.backward(dout.double().reshape(B, L, D))
+    got, stats = ops().attention_fwd(qkv.to(DEV), B, L, H, False, want_stats=True)
+    check("fwd", got.reshape(B, L, D), o, 2 ** -6, 8e-3)
+    dq = ops().attention_bwd(qkv.to(DEV), got, dout.to(DEV), stats, B, L, H, False)
+    check("dqkv", dq.reshape(B, L, 3 * D), x.grad, 2 ** -5, 2e-2)
+    with pytest.raises(RuntimeError, match="image towers only"):
+        ops().attention_fwd(qkv.to(DEV), B, L, H, True)
+
+
 @pytest.mark.parametrize("dh", [64, 80])
 @pytest.mark.parametrize("B,H,L,causal", [(2, 2, 577, False), (1, 3, 401, False), (1, 2, 300, True), (1, 1, 1024, False)])
 def test_attention_long_sequences(B, H, L, causal, dh):
