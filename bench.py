@@ -78,7 +78,8 @@ def kernel_entry(v, steps):
 
 def plan_keep(budget, layers_v, layers_t, mv_b, mt_b, lv_b, lt_b):
     """Spend `budget` bytes of HBM on kept activations where a byte saves the most recompute FLOPs: "medium" tier
-    first (image tower, then text), then upgrades medium -> "light".  -> (light_v, light_t, medium_v, medium_t)."""
+    first (image tower, then text), then upgrades medium -> the tier whose bytes per block are lv_b / lt_b ("light8" for the
+    bf16 engines, "light" for fp8).  -> (upgraded_v, upgraded_t, medium_v, medium_t)."""
     budget = max(0, int(budget))
     mv = min(layers_v, budget // mv_b); budget -= mv * mv_b
     mt = min(layers_t, budget // mt_b); budget -= mt * mt_b
@@ -158,6 +159,10 @@ def main():
     ap.add_argument("--keep-blocks", default="auto", help="'auto' or 'LV,LT[,MV,MT]': light-kept (and medium-kept) blocks per tower (image, text)")
     ap.add_argument("--keep-fraction", type=float, default=None,
                     help="share of the free HBM 'auto' may spend (default 0.93 single process, 0.90 with several ranks; a trial step + vote backs the plan off)")
+    ap.add_argument("--no-light8", action="store_true",
+                    help="upgrade medium-kept blocks to the bf16 'light' tier instead of 'light8' (e4m3 pre-activations)")
+    ap.add_argument("--alloc-conf", default=None,
+                    help="PyTorch caching-allocator settings applied before the first allocation, e.g. expandable_segments:True")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shapes", action="store_true", help="also report time and TF/s per GEMM / attention shape (stderr)")
     ap.add_argument("--accum-freq", type=int, default=1,
@@ -188,6 +193,8 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible - the MI355X engine has no CPU fallback", file=sys.stderr)
         sys.exit(2)
+    if args.alloc_conf:
+        torch.cuda.memory._set_allocator_settings(args.alloc_conf)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -278,9 +285,17 @@ def main():
     # Activation policy: every block recomputes in backward (the reference's --grad-checkpointing) except the
     # first `keep` blocks of each tower, which keep their GEMM / attention outputs in the HBM that is left over.
     # "auto" measures the peak of one all-recompute step and spends ~85 % of the remaining HBM.
+    # the upgraded tier: "light8" (MLP pre-activation kept as e4m3 bytes, 4 D bytes per token on top of the medium set) for
+    # the bf16 engines; the fp8 engine's GEMM has no such epilogue and keeps the bf16 pre-activation ("light", 8 D bytes)
+    use_l8 = args.precision != "fp8" and not args.no_light8
+
     def set_keep(kv, kt, mv=0, mt=0):
-        model.visual.transformer.keep_blocks, model.transformer.keep_blocks = kv, kt
-        model.visual.transformer.medium_blocks, model.transformer.medium_blocks = mv, mt
+        vtr, ttr = model.visual.transformer, model.transformer
+        if use_l8:
+            vtr.light8_blocks, ttr.light8_blocks, vtr.keep_blocks, ttr.keep_blocks = kv, kt, 0, 0
+        else:
+            vtr.keep_blocks, ttr.keep_blocks, vtr.light8_blocks, ttr.light8_blocks = kv, kt, 0, 0
+        vtr.medium_blocks, ttr.medium_blocks = mv, mt
 
     keep_v = keep_t = med_v = med_t = 0
     backoffs = 0
@@ -303,7 +318,8 @@ def main():
         # attention, out-proj: ~17.5 of a block's 25.5 D^2 units for 5 D bytes per token), image tower before
         # text (wider), then upgrades medium -> "light" (the remaining 8 units for 4 more D bytes).
         mv_b, mt_b = vt.medium_keep_bytes(B // A * L_img), tt.medium_keep_bytes(B // A * args.ctx)     # per micro-batch
-        lv_b, lt_b = vt.light_keep_bytes(B // A * L_img), tt.light_keep_bytes(B // A * args.ctx)
+        lv_b, lt_b = (vt.light8_keep_bytes(B // A * L_img), tt.light8_keep_bytes(B // A * args.ctx)) if use_l8 else \
+            (vt.light_keep_bytes(B // A * L_img), tt.light_keep_bytes(B // A * args.ctx))
 
         def plan(budget):
             return plan_keep(budget, cfg["vision_cfg"]["layers"], cfg["text_cfg"]["layers"], mv_b, mt_b, lv_b, lt_b)
@@ -480,10 +496,10 @@ def main():
             "config": {"workload": f"{args.model}@{args.image_size} + text-{args.ctx}, local batch {B}, "
                                    f"global batch {B * world}, " + (f"accum_freq {A} (feature cache: +1 forward per pair), " if A > 1 else "") +
                                    f"InfoNCE local_loss+gather_with_grad, AdamW, "
-                                   f"block recompute except {int(keep_v)}+{int(keep_t)} light-kept and {int(med_v)}+{int(med_t)} medium-kept (image+text) blocks", "precision": args.precision, "parallelism": f"dp{world}" + ("" if args.optimizer == "adamw" else f" zero1/{args.exchange}"),
+                                   f"block recompute except {int(keep_v)}+{int(keep_t)} {'light8' if use_l8 else 'light'}-kept and {int(med_v)}+{int(med_t)} medium-kept (image+text) blocks", "precision": args.precision, "parallelism": f"dp{world}" + ("" if args.optimizer == "adamw" else f" zero1/{args.exchange}"),
                        "global_batch": B * world, "train_gflop_per_pair": round(gf, 2)},
             "model_flops_util": round(pairs_s / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4),
-            "loss": round(last_loss, 4), "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
+            "alloc_conf": args.alloc_conf, "loss": round(last_loss, 4), "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
             "peak_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2**30, 1),
             "alloc_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)),
             "keep_plan_backoffs": backoffs,

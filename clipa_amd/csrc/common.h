@@ -159,6 +159,32 @@ __device__ __forceinline__ float act_bwd(float x) {  // d act(x) / dx
   }
 }
 
+// 8 fp32 values -> 8 e4m3 bytes (OCP, round to nearest even), SATURATING at +-448: a pre-activation beyond the format's range
+// must not become NaN (e4m3 has no infinity).  And back (exact: every e4m3 value is a bf16 value).
+__device__ __forceinline__ u32x2 e4m3x8_sat(const float* f) {
+  float c[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) c[i] = __builtin_amdgcn_fmed3f(f[i], -448.0f, 448.0f);
+  int w0 = 0, w1 = 0;
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], w0, false);
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], w0, true);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], w1, false);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], w1, true);
+  u32x2 q;
+  q[0] = (unsigned)w0;
+  q[1] = (unsigned)w1;
+  return q;
+}
+__device__ __forceinline__ void e4m3x8_to_f32(const u32x2 q, float* f) {
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const f32x2v lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)q[h], false);
+    const f32x2v hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)q[h], true);
+    f[4 * h + 0] = lo.x; f[4 * h + 1] = lo.y; f[4 * h + 2] = hi.x; f[4 * h + 3] = hi.y;
+  }
+}
+
 // ---- wave-level reductions (64 lanes) -------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -22,6 +22,8 @@ struct NTArgs {
   int epi, act;
   int abl;   // experiment flags (clipa_internal_debug_set): 1 no global stores, 2 no epilogue, 8 row-major tile order
   int gm;    // A panels per tile group (nt_group_size)
+  int pre8;  // gemm_nta: C2 is an e4m3 copy of the pre-activation (1 byte per element, row stride ldc BYTES) - CLIPA_EPI_ACT_PRE8
+  int aux8;  // gemm_nta: aux holds e4m3 bytes (row stride ldaux BYTES) - CLIPA_EPI_DACT8
 };
 
 // Tile order of the persistent NT kernels: an XCD walks groups of `gm` A panels, N-tile major inside a group.  More panels per
@@ -93,6 +95,20 @@ __device__ __forceinline__ u32x4 epi_chunk(int epi, u32x4 v, u32x4 av) {
   float f[8], a[8];
   unpack8(v, f);
   unpack8(av, a);
+  if (epi == CLIPA_EPI_ADD) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] += a[i];
+  } else {
+    epi_apply<ACT, LOCK>(epi, f, a);
+  }
+  return pack8(f);
+}
+
+// the same with the second operand already in fp32 (e4m3 pre-activations, CLIPA_EPI_DACT8)
+template <int ACT, int LOCK = 4>
+__device__ __forceinline__ u32x4 epi_chunk_f(int epi, u32x4 v, const float* a) {
+  float f[8];
+  unpack8(v, f);
   if (epi == CLIPA_EPI_ADD) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) f[i] += a[i];

@@ -354,7 +354,12 @@ extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, co
   if (M <= 0 || N <= 0) return CLIPA_OK;
   if (K <= 0 || K % 8 != 0) { clipa_set_error("gemm_nt: K=%ld must be a positive multiple of 8", (long)K); return CLIPA_ERR_ARG; }
   if (N % 8 != 0 || ldc % 8 != 0 || lda % 8 != 0 || ldb % 8 != 0) { clipa_set_error("gemm_nt: N, lda, ldb, ldc must be multiples of 8"); return CLIPA_ERR_ARG; }
-  if (epi < CLIPA_EPI_NONE || epi > CLIPA_EPI_DACT) { clipa_set_error("gemm_nt: unknown epilogue %d", epi); return CLIPA_ERR_ARG; }
+  if (epi < CLIPA_EPI_NONE || epi > CLIPA_EPI_DACT8) { clipa_set_error("gemm_nt: unknown epilogue %d", epi); return CLIPA_ERR_ARG; }
+  // e4m3 pre-activation flavours: the same epilogues with a 1-byte second output / operand, four-wave kernel only
+  const int pre8 = epi == CLIPA_EPI_ACT_PRE8, aux8 = epi == CLIPA_EPI_DACT8;
+  if (pre8 && !C2) { clipa_set_error("gemm_nt: CLIPA_EPI_ACT_PRE8 needs C2"); return CLIPA_ERR_ARG; }
+  if (pre8) epi = CLIPA_EPI_ACT;
+  if (aux8) epi = CLIPA_EPI_DACT;
   if ((epi == CLIPA_EPI_ADD || epi == CLIPA_EPI_DACT) && (!aux || ldaux % 8 != 0)) { clipa_set_error("gemm_nt: epilogue %d needs aux with ldaux%%8==0", epi); return CLIPA_ERR_ARG; }
   if (C2 && epi != CLIPA_EPI_ACT) { clipa_set_error("gemm_nt: C2 (pre-activation copy) goes with CLIPA_EPI_ACT only"); return CLIPA_ERR_ARG; }
   if (out_f32 && epi != CLIPA_EPI_NONE) { clipa_set_error("gemm_nt: f32 output supports epilogue NONE only"); return CLIPA_ERR_ARG; }
@@ -367,6 +372,7 @@ extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, co
   a.A = (const char*)A; a.B = (const char*)B; a.C = (char*)C; a.C2 = (char*)C2; a.bias = bias; a.aux = (const char*)aux;
   a.M = (int)M; a.N = (int)N; a.K = (int)K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
   a.alpha = alpha; a.epi = epi; a.act = act; a.abl = g_abl.load(std::memory_order_relaxed);
+  a.pre8 = pre8; a.aux8 = aux8;
   a.gm = nt_group_size((N + BN - 1) / BN, 256L * K * 2);
   if ((a.abl >> 20) & 63) a.gm = (a.abl >> 20) & 63;       // experiment: tile-group size override (clipa_internal_debug_set flags bits 20..25)
   hipStream_t st = (hipStream_t)stream;
@@ -377,6 +383,7 @@ extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, co
   g_last_gemm.store(1, std::memory_order_relaxed);
   if (variant != 1 && !(a.abl & 13 & 0xfffff) && nta_eligible(a, out_f32))
     return nta_launch(a, dev, num_cu, variant >= 2 ? variant - 2 : NTA_DEFAULT_SCHEDULE, st);
+  if (pre8 || aux8) { clipa_set_error("gemm_nt: e4m3 pre-activation epilogues need whole 256 x 256 x 128 tiles (M=%ld N=%ld K=%ld)", (long)M, (long)N, (long)K); return CLIPA_ERR_ARG; }
   const long tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   if (out_f32) {
     const unsigned grid = (unsigned)(tiles < num_cu ? tiles : num_cu);

@@ -198,3 +198,56 @@ extern "C" int clipa_layernorm_fwd_q8(const void* x, const float* gamma, const f
   else hipLaunchKernelGGL((ln_fwd_q8_kernel<4>), grid, block, 0, st, xp, gamma, beta, (char*)y, (char*)q, dq, (long)rows, (int)D, eps);
   return clipa_check_launch("layernorm_fwd_q8");
 }
+
+// ---- e4m3 pre-activations (the "light8" keep tier; gemm_nta's CLIPA_EPI_ACT_PRE8 / CLIPA_EPI_DACT8 write and read the same bytes) ----
+namespace {
+__global__ void bf16_to_e4m3_kernel(const unsigned short* __restrict__ in, unsigned char* __restrict__ out, long n8) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float f[8];
+    unpack8(*(const u32x4*)(in + 8 * i), f);
+    *(u32x2*)(out + 8 * i) = e4m3x8_sat(f);
+  }
+}
+template <bool ACTIVATE>
+__global__ void e4m3_to_bf16_kernel(const unsigned char* __restrict__ in, unsigned short* __restrict__ out, long n8, int act) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float f[8];
+    e4m3x8_to_f32(*(const u32x2*)(in + 8 * i), f);
+    if (ACTIVATE) {
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const f32x2 x = {f[j], f[j + 1]};
+        const f32x2 r = act == ACT_GELU_ERF ? act_fwd2<ACT_GELU_ERF>(x) : (act == ACT_GELU_TANH ? act_fwd2<ACT_GELU_TANH>(x) : act_fwd2<ACT_QUICK_GELU>(x));
+        f[j] = r.x;
+        f[j + 1] = r.y;
+      }
+    }
+    *(u32x4*)(out + 8 * i) = pack8(f);
+  }
+}
+unsigned cast_grid(long n8) { const long b = (n8 + 255) / 256; return (unsigned)(b < 1 ? 1 : (b > 65536 ? 65536 : b)); }
+int cast_args(const char* what, const void* in, const void* out, int64_t n) {
+  if (n % 8 != 0 || ((size_t)in & 7) || ((size_t)out & 7)) { clipa_set_error("%s: n must be a multiple of 8 and the buffers 8-byte aligned", what); return CLIPA_ERR_ARG; }
+  return 0;
+}
+}  // namespace
+
+extern "C" int clipa_cast_bf16_to_e4m3(const void* in, void* out, int64_t n, void* stream) {
+  if (n <= 0) return CLIPA_OK;
+  if (int rc = cast_args("cast_bf16_to_e4m3", in, out, n)) return rc;
+  hipLaunchKernelGGL(bf16_to_e4m3_kernel, dim3(cast_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)in, (unsigned char*)out, (long)(n / 8));
+  return clipa_check_launch("cast_bf16_to_e4m3");
+}
+extern "C" int clipa_cast_e4m3_to_bf16(const void* in, void* out, int64_t n, void* stream) {
+  if (n <= 0) return CLIPA_OK;
+  if (int rc = cast_args("cast_e4m3_to_bf16", in, out, n)) return rc;
+  hipLaunchKernelGGL(e4m3_to_bf16_kernel<false>, dim3(cast_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)in, (unsigned short*)out, (long)(n / 8), 0);
+  return clipa_check_launch("cast_e4m3_to_bf16");
+}
+extern "C" int clipa_activation_fwd_e4m3(const void* x8, void* out, int64_t n, int act, void* stream) {
+  if (n <= 0) return CLIPA_OK;
+  if (int rc = cast_args("activation_fwd_e4m3", x8, out, n)) return rc;
+  if (act < ACT_GELU_ERF || act > ACT_QUICK_GELU) { clipa_set_error("activation_fwd_e4m3: unknown activation %d", act); return CLIPA_ERR_ARG; }
+  hipLaunchKernelGGL(e4m3_to_bf16_kernel<true>, dim3(cast_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)x8, (unsigned short*)out, (long)(n / 8), act);
+  return clipa_check_launch("activation_fwd_e4m3");
+}

@@ -66,8 +66,11 @@ def _like_param(g, p):
 def _block_forward(x, P, cfg, keep):
     """x [M,D] bf16. P: dict of operand tensors. Returns y and (if keep) the intermediates.
     keep: False (nothing), True / "full" (everything the backward reads), "light" (only the GEMM / attention
-    outputs qkv, a, stats, x1, hpre - LayerNorm outputs and the activation are re-materialised in backward) or
-    "medium" (light without hpre, 10 instead of 18 bytes per element of x: backward re-runs LN2 + the c_fc GEMM,
+    outputs qkv, a, stats, x1, hpre - LayerNorm outputs and the activation are re-materialised in backward),
+    "light8" (light with hpre kept as saturating e4m3 bytes written by the c_fc epilogue itself: 14 instead of 18 bytes
+    per element of x; the backward takes gelu'(h) and the re-materialised activation from the e4m3 value - ~3 % rms
+    rounding of h, the only tier whose gradients are not bit-identical to the recomputed block's) or
+    "medium" (light without hpre, 10 bytes per element of x: backward re-runs LN2 + the c_fc GEMM,
     a third of the block's forward FLOPs, and skips the other three GEMMs and attention)."""
     B, L, H, causal, act = cfg["B"], cfg["L"], cfg["H"], cfg["causal"], cfg["act"]
     if cfg.get("fp8"):
@@ -81,11 +84,11 @@ def _block_forward(x, P, cfg, keep):
     x1 = ops.gemm_nt(a, P["w_out"], P["b_out"], epi=ops.EPI_ADD, aux=x)
     h2 = ops.layernorm_fwd(x1, P["ln2_w"], P["ln2_b"], cfg["eps"])
     if keep and keep != "medium":
-        g, hpre = ops.gemm_nt(h2, P["w_fc"], P["b_fc"], epi=ops.EPI_ACT, act=act, want_pre=True)
+        g, hpre = ops.gemm_nt(h2, P["w_fc"], P["b_fc"], epi=ops.EPI_ACT, act=act, want_pre="e4m3" if keep == "light8" else True)
     else:
         g, hpre = ops.gemm_nt(h2, P["w_fc"], P["b_fc"], epi=ops.EPI_ACT, act=act), None
     y = ops.gemm_nt(g, P["w_proj"], P["b_proj"], epi=ops.EPI_ADD, aux=x1)
-    if keep in ("light", "medium"):
+    if keep in ("light", "light8", "medium"):
         return y, (None, qkv, a, stats, x1, None, hpre, None)
     if keep:
         return y, (h1, qkv, a, stats, x1, h2, hpre, g)
@@ -112,6 +115,8 @@ def _block_forward_fp8(x, P, cfg, keep):
     clipa_quantize_rows; everything between the GEMMs (residual stream, attention, softmax statistics, kept tensors) is
     bf16 exactly as in the bf16 engine, and the weight gradients stay bf16 GEMMs of bf16 tensors."""
     B, L, H, causal, act = cfg["B"], cfg["L"], cfg["H"], cfg["causal"], cfg["act"]
+    if keep == "light8":          # the e4m3 pre-activation copy is an epilogue of the bf16 GEMM only: plain light keep here
+        keep = "light"
     full = bool(keep) and keep not in ("light", "medium")
     h1, q1, s1 = ops.layernorm_fwd_q8(x, P["ln1_w"], P["ln1_b"], cfg["eps"], want_bf16=full)
     qkv = _lin8(q1, s1, P, "in")

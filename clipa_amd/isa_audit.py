@@ -59,13 +59,19 @@ def store_data_races(path, txt, label=r"^(\w[\w.$]*):"):
 def epilogue_store_counts(path, txt):
     """gemm_nta_kernel<EPI, PRE, .> / gemm_f8a_kernel<EPI, PRE, .>: every epilogue copy (between its `; CLIPA_EPI_BEGIN k` and
     `; CLIPA_EPI_END k` markers, one straight-line block) holds exactly the 16-byte stores the tile statement's wait assumes:
-    32 per output.  hipcc's structurizer makes a path walk over the basic blocks useless (correlated flow predicates), and
+    32 per output (the e4m3 pre-activation copy of gemm_nta<., PRE = 2> leaves as 32 8-byte stores).  hipcc's structurizer makes a path walk over the basic blocks useless (correlated flow predicates), and
     totals per kernel say nothing (it tail-merges identical stores of the three activation copies) - hence the markers."""
-    problems, kernel, open_k, count, copies = [], None, None, 0, 0
+    problems, kernel, open_k, count, count8, copies = [], None, None, 0, 0, 0
 
     def want(kname):
-        m = re.search(r"gemm_(?:nta|f8a)_kernelILi(\d+)ELb([01])E", kname)
-        return 32 * (2 if m and m.group(2) == "1" else 1)
+        """-> (16-byte stores, 8-byte stores) per epilogue copy.  gemm_nta_kernel<EPI, PRE (0 / 1 bf16 copy / 2 e4m3 copy), AUX8,
+        SCHED>, gemm_f8a_kernel<EPI, PRE (bool), FMT>."""
+        m = re.search(r"gemm_nta_kernelILi(\d+)ELi(\d+)E", kname)
+        if m:
+            pre = int(m.group(2))
+            return 32 * (2 if pre == 1 else 1), 32 if pre == 2 else 0
+        m = re.search(r"gemm_f8a_kernelILi(\d+)ELb([01])E", kname)
+        return 32 * (2 if m and m.group(2) == "1" else 1), 0
 
     def close_kernel():
         if kernel is not None and copies == 0:
@@ -77,7 +83,7 @@ def epilogue_store_counts(path, txt):
         m = re.match(r"^(_ZN\S*gemm_(?:nta|f8a)_kernel\S*):", line)
         if m:
             close_kernel()
-            kernel, open_k, count, copies = m.group(1), None, 0, 0
+            kernel, open_k, count, count8, copies = m.group(1), None, 0, 0, 0
             continue
         if line.startswith(".Lfunc_end"):
             close_kernel()
@@ -89,18 +95,20 @@ def epilogue_store_counts(path, txt):
         if m and m.group(1) == "BEGIN":
             if open_k is not None:
                 problems.append(f"{path}:{ln}: {kernel}: nested CLIPA_EPI_BEGIN")
-            open_k, count = m.group(2), 0
+            open_k, count, count8 = m.group(2), 0, 0
         elif m:
             if open_k != m.group(2):
                 problems.append(f"{path}:{ln}: {kernel}: CLIPA_EPI_END {m.group(2)} does not close BEGIN {open_k}")
-            elif count != want(kernel):
-                problems.append(f"{path}:{ln}: {kernel}: epilogue copy {open_k} issues {count} buffer_store_dwordx4, the tile "
-                                f"statement's vmcnt assumes {want(kernel)}")
+            elif (count, count8) != want(kernel):
+                problems.append(f"{path}:{ln}: {kernel}: epilogue copy {open_k} issues {count} buffer_store_dwordx4 + {count8} "
+                                f"buffer_store_dwordx2, the tile statement's vmcnt assumes {want(kernel)}")
             open_k, copies = None, copies + 1
         elif open_k is not None:
             code = s.split(";")[0].strip()
             if re.match(r"buffer_store_dwordx4\b", code):
                 count += 1
+            elif re.match(r"buffer_store_dwordx2\b", code):
+                count8 += 1
             elif re.match(r"(buffer|global|flat)_store_", code):
                 problems.append(f"{path}:{ln}: {kernel}: store of another width inside the epilogue: `{code}`")
             elif re.match(r"\.LBB\w+:", s) or code.startswith("s_cbranch") or code.startswith("s_branch") or code.startswith("s_setpc"):

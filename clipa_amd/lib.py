@@ -52,6 +52,9 @@ SIGNATURES = {
     "clipa_cast_bf16_to_f32": (_I32, [_P, _P, _I64, _P]),
     "clipa_transpose_to_bf16": (_I32, [_P, _I32, _P, _I64, _I64, _I64, _I64, _P]),
     "clipa_activation_fwd": (_I32, [_P, _P, _I64, _I32, _P]),
+    "clipa_cast_bf16_to_e4m3": (_I32, [_P, _P, _I64, _P]),
+    "clipa_cast_e4m3_to_bf16": (_I32, [_P, _P, _I64, _P]),
+    "clipa_activation_fwd_e4m3": (_I32, [_P, _P, _I64, _I32, _P]),
     "clipa_simce_workspace": (_I64, [_I64, _I64]),
     "clipa_simce_fwd": (_I32, [_P, _P, _I64, _I64, _I64, _I64, _I64, _P, _I64, _P, _P, _P, _I64, _P]),
     "clipa_simce_bwd": (_I32, [_P, _P, _I64, _I64, _I64, _I64, _I64, _P, _I64, _F, _P, _P, _I64, _P, _P, _I64, _P]),

@@ -150,6 +150,10 @@ class Transformer(nn.Module):
         # ... and the next `medium_blocks` blocks keep the same set minus the MLP pre-activation (~10*D bytes per
         # token) and re-run only LN2 + c_fc in backward.
         self.medium_blocks = 0
+        # ... and `light8_blocks` blocks in between keep the light set with the MLP pre-activation as e4m3 bytes (~14*D bytes
+        # per token): no GEMM is re-run, gelu'(h) and the re-materialised activation come from the rounded value
+        # (engine._block_forward).  Order of the tiers along the depth: light, light8, medium, recompute.
+        self.light8_blocks = 0
         # fp8 engine mode (create_model(precision="fp8"), BASELINE.json configs[3]): the four linear layers of every block run
         # forward and input-gradient GEMMs on e4m3 operands (engine._block_forward_fp8); "e5m2" switches the gradient operand
         self.fp8 = False
@@ -166,14 +170,19 @@ class Transformer(nn.Module):
                 "recompute": bool(self.grad_checkpointing), "keep": "light", "fp8": bool(self.fp8),
                 "fp8_grad_fmt": ops.FMT_E5M2 if self.fp8_grad_format == "e5m2" else ops.FMT_E4M3}
         kept, medium = dict(base, keep_this=True), dict(base, keep_this=True, keep="medium")
+        light8 = dict(base, keep_this=True, keep="light8")
+        n1, n2 = self.keep_blocks, self.keep_blocks + self.light8_blocks
         for i, blk in enumerate(self.resblocks):
-            cfg = kept if i < self.keep_blocks else (medium if i < self.keep_blocks + self.medium_blocks else base)
+            cfg = kept if i < n1 else (light8 if i < n2 else (medium if i < n2 + self.medium_blocks else base))
             x = engine.ResBlockFn.apply(x, cfg, cache, *blk.param_tuple())
         return x
 
     def light_keep_bytes(self, tokens):
         """HBM bytes one kept block holds between forward and backward for `tokens` rows."""
         return tokens * 9 * self.width * 2 + tokens * self.heads * 8   # qkv, a, x1, hpre (bf16) + softmax stats
+
+    def light8_keep_bytes(self, tokens):
+        return tokens * 7 * self.width * 2 + tokens * self.heads * 8   # qkv, a, x1 (bf16), hpre (e4m3: 4 * width bytes) + stats
 
     def medium_keep_bytes(self, tokens):
         return tokens * 5 * self.width * 2 + tokens * self.heads * 8   # qkv, a, x1 (bf16) + softmax stats

@@ -93,9 +93,47 @@ def _rowmajor(t):
     return t, t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
 
 
+EPI_ACT_PRE8, EPI_DACT8 = 4, 5      # include/clipa_hip.h: e4m3 pre-activation copy / e4m3 second operand (whole-tile shapes)
+
+
+def _whole_tiles(M, N, K):
+    """Shapes the four-wave GEMM kernel takes (gemm_nta.hip: nta_eligible): the fused e4m3 epilogues exist only there."""
+    return M % 256 == 0 and N % 256 == 0 and K % 128 == 0 and K >= 256
+
+
+def cast_e4m3(x):
+    """bf16 -> saturating OCP e4m3 bytes (uint8, same shape): the unfused form of gemm_nt(..., want_pre="e4m3")."""
+    _chk(x, bf16, "x")
+    x = x.contiguous()
+    out = torch.empty(x.shape, device=x.device, dtype=u8)
+    with _Timed("cast_e4m3", 0.0, 3.0 * x.numel()):
+        lib.call("clipa_cast_bf16_to_e4m3", _p(x), _p(out), x.numel(), _stream())
+    return out
+
+
+def e4m3_to_bf16(x8):
+    """e4m3 bytes (uint8) -> bf16 (exact)."""
+    _chk(x8, u8, "x8")
+    x8 = x8.contiguous()
+    out = torch.empty(x8.shape, device=x8.device, dtype=bf16)
+    with _Timed("cast_e4m3", 0.0, 3.0 * x8.numel()):
+        lib.call("clipa_cast_e4m3_to_bf16", _p(x8), _p(out), x8.numel(), _stream())
+    return out
+
+
 def gemm_nt(a, b, bias=None, *, epi=EPI_NONE, act=ACT_GELU_ERF, aux=None, alpha=1.0, out_f32=False,
             want_pre=False, out=None):
-    """C[M,N] = epi(alpha * a[M,K] @ b[N,K]^T + bias). a, b bf16; bias f32 [N]."""
+    """C[M,N] = epi(alpha * a[M,K] @ b[N,K]^T + bias). a, b bf16; bias f32 [N].
+    want_pre: True -> also the bf16 pre-activation; "e4m3" -> it as saturating e4m3 bytes (uint8 [M,N], the "light8" keep tier:
+    fused into the epilogue on whole-tile shapes, GEMM + cast otherwise).  aux of EPI_DACT may be such a uint8 tensor."""
+    if want_pre == "e4m3" and not (epi == EPI_ACT and not out_f32 and _whole_tiles(a.shape[0], b.shape[0], a.shape[1])):
+        o, pre = gemm_nt(a, b, bias, epi=epi, act=act, aux=aux, alpha=alpha, want_pre=True, out=out)
+        return o, cast_e4m3(pre)
+    if aux is not None and aux.dtype == u8:
+        if epi != EPI_DACT:
+            raise RuntimeError("gemm_nt: an e4m3 (uint8) second operand goes with EPI_DACT only")
+        if not _whole_tiles(a.shape[0], b.shape[0], a.shape[1]):
+            aux = e4m3_to_bf16(aux)
     _chk(a, bf16, "a", 2)
     _chk(b, bf16, "b", 2)
     a, lda = _rowmajor(a)
@@ -109,14 +147,25 @@ def gemm_nt(a, b, bias=None, *, epi=EPI_NONE, act=ACT_GELU_ERF, aux=None, alpha=
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=f32 if out_f32 else bf16)
     ldc = out.stride(0) if M > 1 else N
-    pre = torch.empty((M, N), device=a.device, dtype=bf16) if want_pre else None
-    ldaux = 0
-    if aux is not None:
+    pre8 = want_pre == "e4m3"
+    pre = torch.empty((M, N), device=a.device, dtype=u8 if pre8 else bf16) if want_pre else None
+    if pre8 and ldc != N:
+        raise RuntimeError("gemm_nt: want_pre='e4m3' needs a dense output (the copy shares its row stride)")
+    ldaux, aux_sz = 0, 2
+    if aux is not None and aux.dtype == u8:
+        _chk(aux, u8, "aux", 2)
+        aux, ldaux = _rowmajor(aux)
+        epi, aux_sz = EPI_DACT8, 1
+    elif aux is not None:
         _chk(aux, bf16, "aux", 2)
         aux, ldaux = _rowmajor(aux)
+    if pre8:
+        epi = EPI_ACT_PRE8
     osz = 4 if out_f32 else 2
-    nbytes = 2.0 * (M * K + N * K) + osz * M * N + (2.0 * M * N if aux is not None else 0) + (2.0 * M * N if want_pre else 0)
-    with _Timed("gemm_nt", 2.0 * M * N * K, nbytes, f"{M},{N},{K},epi{epi}{'+pre' if want_pre else ''}{',f32' if out_f32 else ''}"):
+    nbytes = 2.0 * (M * K + N * K) + osz * M * N + (float(aux_sz) * M * N if aux is not None else 0) + \
+        ((1.0 if pre8 else 2.0) * M * N if want_pre else 0)
+    tag_epi = {EPI_ACT_PRE8: "1+pre8", EPI_DACT8: "3,aux8"}.get(epi, f"{epi}{'+pre' if want_pre else ''}")
+    with _Timed("gemm_nt", 2.0 * M * N * K, nbytes, f"{M},{N},{K},epi{tag_epi}{',f32' if out_f32 else ''}"):
         lib.call("clipa_gemm_nt", _p(a), _p(b), _p(out), _p(pre), _p(bias), _p(aux), M, N, K, lda, ldb, ldc, ldaux,
                  float(alpha), epi, act, 1 if out_f32 else 0, _stream())
     return (out, pre) if want_pre else out
@@ -545,7 +594,13 @@ def transpose_bf16(t):
 
 
 def activation_fwd(x, act):
-    """bf16 act(x) (gelu erf / tanh / quick)."""
+    """bf16 act(x) (gelu erf / tanh / quick); x bf16, or e4m3 bytes (uint8: the "light8" keep tier's pre-activation)."""
+    if x.dtype == u8:
+        x = x.contiguous()
+        out = torch.empty(x.shape, device=x.device, dtype=bf16)
+        with _Timed("activation_fwd", 0.0, 3.0 * x.numel()):
+            lib.call("clipa_activation_fwd_e4m3", _p(x), _p(out), x.numel(), act, _stream())
+        return out
     _chk(x, bf16, "x")
     x = x.contiguous()
     out = torch.empty_like(x)

@@ -23,6 +23,11 @@ extern "C" {
 #define CLIPA_EPI_ACT 1  /* C = act(v), optional C2 = v (pre-activation, for the backward)    */
 #define CLIPA_EPI_ADD 2  /* C = v + aux            (residual add, transformer.py:248-249)     */
 #define CLIPA_EPI_DACT 3 /* C = v * act'(aux)      (activation backward)                      */
+/* MI355X engine extensions (no reference counterpart): the pre-activation kept as OCP e4m3 bytes (saturating, no scale) - half
+ * the HBM of the bf16 copy.  Whole-tile shapes only (M, N multiples of 256, K multiple of 128, K >= 256): other shapes return
+ * CLIPA_ERR_ARG and the caller composes CLIPA_EPI_ACT + clipa_cast_bf16_to_e4m3 / clipa_cast_e4m3_to_bf16 + CLIPA_EPI_DACT. */
+#define CLIPA_EPI_ACT_PRE8 4 /* C = act(v), C2 = e4m3(v): uint8 [M, ldc]                      */
+#define CLIPA_EPI_DACT8 5    /* C = v * act'(aux), aux = e4m3 bytes, uint8 [M, ldaux]          */
 /* activations: nn.GELU(approximate='none'|'tanh') (model.py:128-129), QuickGELU (transformer.py:37-40) */
 #define CLIPA_ACT_GELU_ERF 0
 #define CLIPA_ACT_GELU_TANH 1
@@ -48,6 +53,12 @@ int clipa_version(void);
 int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux,
                   int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldaux,
                   float alpha, int epi, int act, int out_f32, void* stream);
+
+/* e4m3 pre-activations ("light8" keep tier): bf16 -> saturating OCP e4m3 bytes and back (exact), and act(e4m3 x) -> bf16
+ * (the re-materialisation of the MLP activation in backward: transformer.py:217-219 `gelu`). */
+int clipa_cast_bf16_to_e4m3(const void* in, void* out, int64_t n, void* stream);
+int clipa_cast_e4m3_to_bf16(const void* in, void* out, int64_t n, void* stream);
+int clipa_activation_fwd_e4m3(const void* x8, void* out, int64_t n, int act, void* stream);
 
 /* out[R,C] = sum_m P[m,R] * Q[m,C]  (weight gradients dW = dY^T . X of the same layers; also the
  * gathered-feature gradients of loss.py:135-139).  out is f32 or bf16. workspace: split-M partial slabs. */

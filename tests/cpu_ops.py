@@ -26,6 +26,14 @@ def _dact(x, a):
     return x.grad
 
 
+def _e4m3(x):
+    return x.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+
+
+def _from_e4m3(x8):
+    return x8.view(torch.float8_e4m3fn).float()
+
+
 def gemm_nt(a, b, bias=None, *, epi=EPI_NONE, act=0, aux=None, alpha=1.0, out_f32=False, want_pre=False, out=None):
     v = (a.float() @ b.float().T) * alpha
     if bias is not None:
@@ -33,7 +41,9 @@ def gemm_nt(a, b, bias=None, *, epi=EPI_NONE, act=0, aux=None, alpha=1.0, out_f3
     if out_f32:
         return v
     v = v.to(bf16)
-    pre = v
+    pre = _e4m3(v) if want_pre == "e4m3" else v
+    if aux is not None and aux.dtype == torch.uint8:
+        aux = _from_e4m3(aux)
     if epi == EPI_ACT:
         v = _act(v.float(), act).to(bf16)
     elif epi == EPI_ADD:
@@ -192,6 +202,8 @@ def transpose_bf16(t):
 
 
 def activation_fwd(x, act):
+    if x.dtype == torch.uint8:
+        x = _from_e4m3(x)
     return _act(x.float(), act).to(bf16)
 
 

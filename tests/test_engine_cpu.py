@@ -115,6 +115,36 @@ def test_recompute_equals_stored(golden):
             assert torch.equal(p.grad, r.grad), k
 
 
+def test_light8_tier_keeps_the_forward_and_stays_close_in_backward(golden):
+    """"light8" keep tier (the MLP pre-activation kept as saturating e4m3 bytes, VERDICT r3 next #5a): the forward is the
+    recomputed block's bit for bit (the copy is a side output), the backward reads gelu'(h) and re-materialises gelu(h) from
+    the rounded h (~3 % rms per element, unbiased: it averages out over the tokens a weight gradient sums).  Stated tolerance
+    against the all-recompute gradients at toy size (80 image tokens, a handful of them carrying the gradient): per-tensor
+    cosine >= 0.997 (measured worst 0.9989: c_proj.weight, whose operand gelu(h) carries the rounding directly), norm within
+    2 %; the BASELINE-dimension numbers are in tests/test_model_gpu.py."""
+    g = golden
+    ma, oa, la = _run(g, recompute=True)
+    m8 = clipa_amd.CLIP(**g.cfg, output_dict=True)
+    m8.load_state_dict(g.sd, strict=True)
+    m8.set_grad_checkpointing(True)
+    for t in (m8.visual.transformer, m8.transformer):
+        t.light8_blocks = t.layers
+    o8 = m8(g.images_u8, g.texts)
+    l8 = clipa_amd.ClipLoss()(**o8, output_dict=True)["contrastive_loss"]
+    l8.backward()
+    assert float(la) == float(l8) and torch.equal(oa["image_features"], o8["image_features"])
+    worst = 1.0
+    for (k, p), (_, q) in zip(ma.named_parameters(), m8.named_parameters()):
+        if p.grad is None or p.grad.numel() == 1 or float(p.grad.norm()) < 1e-7:
+            continue
+        a, b = q.grad.double().reshape(-1), p.grad.double().reshape(-1)
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+        worst = min(worst, cos)
+        assert cos > 0.997, (k, cos)
+        assert abs(float(a.norm() / b.norm()) - 1) < 0.02, k
+    print(f"[{g.name}] light8 vs recompute: worst gradient cosine {worst:.6f}")
+
+
 def test_bf16_precision_mode_and_frozen_tower(golden):
     m, _, loss = _run(golden, precision="bf16")
     for k, p in m.named_parameters():

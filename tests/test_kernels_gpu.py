@@ -136,6 +136,49 @@ def test_gemm_nta_small_shapes_every_epilogue_bitwise_vs_nt2(M, N, K):
         assert torch.equal(y, z), f"{name}: second launch differs"
 
 
+@pytest.mark.parametrize("M,N,K", [(1024, 768, 512), (512, 1024, 256), (1000, 520, 776)])
+def test_gemm_nt_e4m3_pre_activation_epilogues(M, N, K):
+    """The "light8" keep tier's GEMM flavours (CLIPA_EPI_ACT_PRE8 / CLIPA_EPI_DACT8, fused in gemm_nta on whole-tile shapes; the
+    third shape is ragged and takes the GEMM + cast fallback): the activation output is the plain epilogue's bit for bit,
+    the e4m3 copy of the pre-activation is the saturating round-to-nearest-even e4m3 of the fp32 value (checked against torch's
+    float8_e4m3fn cast of the fp64 product: equal bytes on >= 99 % of the elements - 95 % for the fallback, which rounds the bf16
+    value a second time - and never more than one e4m3 step apart), and GELU-backward from those bytes equals GELU-backward
+    from their exact bf16 values."""
+    o = ops()
+    a, b = rnd(M, K, seed=M + 7), rnd(N, K, seed=N + 8, scale=0.2)
+    bias = rnd(N, seed=5, dtype=f32) * 3
+    A, B, BIAS = a.to(DEV), b.to(DEV), bias.to(DEV)
+    lin = a.double() @ b.double().T + bias.double()
+    act_ref = o.gemm_nt(A, B, BIAS, epi=o.EPI_ACT, act=0)
+    act, pre8 = o.gemm_nt(A, B, BIAS, epi=o.EPI_ACT, act=0, want_pre="e4m3")
+    whole = M % 256 == 0 and N % 256 == 0 and K % 128 == 0
+    assert _last_gemm() == (NTA if whole else NT2)
+    assert pre8.dtype == torch.uint8 and tuple(pre8.shape) == (M, N)
+    assert torch.equal(act, act_ref)
+    want = lin.clamp(-448, 448).float().to(torch.float8_e4m3fn)
+    got = pre8.cpu().view(torch.float8_e4m3fn)
+    same = (got.view(torch.uint8) == want.view(torch.uint8)).float().mean()
+    assert float(same) > (0.99 if whole else 0.95), float(same)      # (the fallback rounds bf16(v): ~3 % double-rounding ties)
+    gf, wf = got.float().double(), want.float().double()
+    assert torch.isfinite(gf).all()
+    step = torch.maximum(wf.abs(), torch.tensor(2.0 ** -6, dtype=torch.float64)) * 2.0 ** -3      # one e4m3 step at that magnitude
+    assert ((gf - wf).abs() <= step * 1.001).all()
+    assert float(gf.abs().max()) <= 448.0 and float(lin.abs().max()) > 30
+    # saturation: a pre-activation beyond the format's range becomes +-448, never NaN
+    big, big8 = o.gemm_nt(A, B, BIAS * 0 + 1000.0, epi=o.EPI_ACT, act=0, want_pre="e4m3", alpha=0.0)
+    assert (big8.cpu().view(torch.float8_e4m3fn).float() == 448.0).all()
+    # GELU backward from the bytes
+    dy = rnd(M, N, seed=11).to(DEV)
+    w2 = rnd(K, N, seed=12, scale=0.05).to(DEV)                      # dh[M, K'] = dy[M,N] @ w2[K',N]^T * gelu'(h8[M, K']) - shapes swapped
+    h8 = o.cast_e4m3(rnd(M, K, seed=13, scale=2.0).to(DEV))
+    hb = o.e4m3_to_bf16(h8)
+    assert torch.equal(o.cast_e4m3(hb), h8)                           # exact round trip
+    d8 = o.gemm_nt(dy, w2, epi=o.EPI_DACT, act=0, aux=h8)
+    d16 = o.gemm_nt(dy, w2, epi=o.EPI_DACT, act=0, aux=hb)
+    assert torch.equal(d8, d16)
+    assert torch.equal(o.activation_fwd(h8, 0), o.activation_fwd(hb, 0))
+
+
 def test_gemm_nt_ragged_shapes_every_epilogue():
     """Ragged M / N / K tails, several tiles per persistent workgroup, every epilogue; the second launch re-uses ring
     state; the one-output and two-output activation epilogues agree bit for bit (a block's recompute relies on it)."""

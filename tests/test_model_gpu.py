@@ -281,6 +281,37 @@ def test_recompute_equals_stored_activations(golden):
         assert torch.equal(ga[True][1][k], ga["mixed"][1][k]), k
 
 
+@pytest.mark.parametrize("case", ["full_L16_224", "full_S16_112_t32", "cls_erf"])
+def test_light8_keep_tier_against_recompute_and_oracle(case):
+    """The "light8" keep tier (MLP pre-activation kept as e4m3 bytes, VERDICT r3 next #5a) on every block, at BASELINE
+    dimensions (ViT-L/16 @ 224, batch 4: 788 image tokens; ViT-S/16 @ 112, batch 64) and at toy size: the forward and the loss
+    are the recomputed step's bit for bit; every parameter gradient against the all-recompute engine (measured: cosine >=
+    0.9997 at BASELINE dimensions, >= 0.9987 at toy size where a handful of tokens carry the gradient) and against the fp32
+    oracle with the engine's stated tolerance (0.99 / 5 %)."""
+    g = load_golden(case)
+    ref_loss, ref = _oracle_grads(g)
+    base = _engine(g)
+    _, l0 = _step(base, g)
+    m = _engine(g)
+    for t in (m.visual.transformer, m.transformer):
+        t.light8_blocks = t.layers
+    out, l8 = _step(m, g)
+    assert float(l8) == float(l0)
+    got = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    rec = {k: p.grad for k, p in base.named_parameters() if p.grad is not None}
+    worst = (1.0, None)
+    for k, a in got.items():
+        a, b = a.double().reshape(-1), rec[k].double().reshape(-1)
+        if a.numel() == 1 or float(b.norm()) < 1e-7:
+            continue
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+        worst = min(worst, (cos, k))
+        assert abs(float(a.norm() / b.norm()) - 1) < 0.02, k
+    print(f"[{case}] light8 vs recompute: worst gradient cosine", worst)
+    assert worst[0] > (0.997 if case == "cls_erf" else 0.9995), worst
+    _compare_gradients(got, ref, case + " light8")
+
+
 def test_input_formats_agree():
     """uint8 NCHW, uint8 channels_last and pre-normalised float inputs give the same features."""
     g = load_golden("cls_erf")

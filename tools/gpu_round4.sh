@@ -19,6 +19,8 @@ for s in $STAGES; do
       timeout 900 python bench.py --shapes > gpurun_out/bench.log 2>&1; echo "rc=$?" >> gpurun_out/bench.log ;;
     benchq)
       timeout 600 python bench.py --shapes --steps 3 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 ${BENCHQ_ARGS:-} > gpurun_out/benchq.log 2>&1; echo "rc=$?" >> gpurun_out/benchq.log ;;
+    benchq2)
+      timeout 600 python bench.py --shapes --steps 3 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 ${BENCHQ2_ARGS:-} > gpurun_out/benchq2.log 2>&1; echo "rc=$?" >> gpurun_out/benchq2.log ;;
     benchdist)
       # the multi-rank code path (RCCL group, DDP, vote-based keep plan, per-rank record) on one GPU
       CLIPA_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29655 \
