@@ -187,8 +187,12 @@ def test_bench_keep_planner_respects_the_budget():
         saved = 25.5 * kv + 17.5 * dv          # recompute units avoided in the image tower
         assert saved >= prev
         prev = saved
-    kv, kt, dv, dt = bench.plan_keep(200 << 30, 24, 12, mv, mt, lv, lt)
-    assert (kv, kt, dv) == (0, 0, 24) and 1 <= dt <= 12            # medium everywhere in the image tower before any upgrade
+    kv, kt, dv, dt = bench.plan_keep(188 << 30, 24, 12, mv, mt, lv, lt)
+    assert (kv, kt, dv) == (0, 0, 24)                              # medium everywhere in the image tower before any upgrade
+    l8v = m.visual.transformer.light8_keep_bytes(tokens_v)
+    assert mv < l8v < lv
+    kv, kt, dv, dt = bench.plan_keep(200 << 30, 24, 12, mv, mt, l8v, m.transformer.light8_keep_bytes(tokens_t))
+    assert kv >= 1 and kv + dv == 24                               # ... then image-tower upgrades before the text tower's turn
     assert bench.plan_keep(2000 << 30, 24, 12, mv, mt, lv, lt) == (24, 12, 0, 0)
 
 

@@ -163,7 +163,7 @@ def test_gemm_nt_e4m3_pre_activation_epilogues(M, N, K):
     assert torch.isfinite(gf).all()
     step = torch.maximum(wf.abs(), torch.tensor(2.0 ** -6, dtype=torch.float64)) * 2.0 ** -3      # one e4m3 step at that magnitude
     assert ((gf - wf).abs() <= step * 1.001).all()
-    assert float(gf.abs().max()) <= 448.0 and float(lin.abs().max()) > 30
+    assert float(gf.abs().max()) <= 448.0 and float(lin.abs().max()) > 8
     # saturation: a pre-activation beyond the format's range becomes +-448, never NaN
     big, big8 = o.gemm_nt(A, B, BIAS * 0 + 1000.0, epi=o.EPI_ACT, act=0, want_pre="e4m3", alpha=0.0)
     assert (big8.cpu().view(torch.float8_e4m3fn).float() == 448.0).all()
