@@ -160,7 +160,7 @@ def main():
                          "configs[3]: bf16 weights / activations, e4m3 operands for the block GEMMs (forward + input gradient)")
     ap.add_argument("--keep-blocks", default="auto", help="'auto' or 'LV,LT[,MV,MT]': light-kept (and medium-kept) blocks per tower (image, text)")
     ap.add_argument("--keep-fraction", type=float, default=None,
-                    help="share of the free HBM 'auto' may spend (default 0.93 single process, 0.90 with several ranks; a trial step + vote backs the plan off)")
+                    help="share of the free HBM 'auto' may spend (default 0.95 single process, 0.90 with several ranks; a trial step + vote backs the plan off)")
     ap.add_argument("--no-light8", action="store_true",
                     help="upgrade medium-kept blocks to the bf16 'light' tier instead of 'light8' (e4m3 pre-activations)")
     ap.add_argument("--alloc-conf", default=None,
@@ -312,7 +312,7 @@ def main():
         peak = torch.cuda.max_memory_allocated(dev)
         # several ranks: a little less than alone (RCCL's channel buffers and the gathered features grow with the world size;
         # the trial below is collective-free), and the vote after the trial backs every rank off together if it was too much
-        frac = args.keep_fraction if args.keep_fraction is not None else (0.90 if dist_on else 0.93)
+        frac = args.keep_fraction if args.keep_fraction is not None else (0.90 if dist_on else 0.95)
         budget0 = int(frac * (total_mem - peak)) - (6 << 30)
         if dist_on:
             budget0 = agree_budget(budget0, dev)
