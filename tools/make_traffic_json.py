@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/traffic.json from a PMC summary (tools/pmc_summary.py output of `tools/gpu_round3.sh pmcbench`):
+"""profiles/traffic.json from a PMC summary (tools/pmc_summary.py output of `tools/gpu_round4.sh pmcbench`):
 
     python tools/make_traffic_json.py gpurun_out/pmcbench_summary.txt "what was measured"
 
@@ -19,9 +19,16 @@ from bench import kernel_source_sha16  # noqa: E402
 def main():
     text = open(sys.argv[1]).read()
     note = sys.argv[2] if len(sys.argv) > 2 else ""
-    per = {}
-    for m in re.finditer(r"^(\S+)\n\s+FETCH_SIZE\s+n=\s*(\d+) mean/dispatch=(\S+)\n\s+WRITE_SIZE\s+n=\s*(\d+) mean/dispatch=(\S+)", text, re.M):
-        per[m.group(1)] = {"FETCH_SIZE": float(m.group(3)), "WRITE_SIZE": float(m.group(5)), "n": int(m.group(2))}
+    per, cur = {}, None
+    for line in text.splitlines():
+        if line and not line[0].isspace():
+            cur = line.strip()
+            continue
+        m = re.match(r"\s+(\S+)\s+n=\s*(\d+) mean/dispatch=(\S+)", line)
+        if m and cur and m.group(1) in ("FETCH_SIZE", "WRITE_SIZE"):
+            per.setdefault(cur, {})[m.group(1)] = float(m.group(3))
+            per[cur]["n"] = int(m.group(2))
+    per = {k: v for k, v in per.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
     nt = {k: v for k, v in per.items() if "gemm_nta_kernel" in k}
     n = sum(v["n"] for v in nt.values())
     fetch = sum(v["FETCH_SIZE"] * v["n"] for v in nt.values()) / n * 1024
@@ -31,7 +38,7 @@ def main():
         "uncorrected_fetch_plus_write_bytes": int(fetch + write),
         "kernel_source_sha16": kernel_source_sha16(),
         "measured": note,
-        "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, counters only; tools/gpu_round3.sh stage pmcbench) over "
+        "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, counters only; tools/gpu_round4.sh stage pmcbench) over "
                   "`python bench.py --steps 1 --warmup 0 --keep-blocks 0,0,24,4`, dispatch-weighted mean over the %d gemm_nta_kernel dispatches of the "
                   "step; read side doubled per MI355X_MICROARCH.md (FETCH_SIZE reports 1/2 of wide coalesced reads on gfx950), WRITE_SIZE taken as "
                   "is.  Fabric-side counters: Infinity-Cache hits are included; the excess over the algorithmic bytes is operand panels re-fetched "
