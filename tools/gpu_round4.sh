@@ -45,10 +45,16 @@ for s in $STAGES; do
         timeout 500 python bench.py --model ViT-H-14 --batch 2048 --precision $prec --steps 2 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 --shapes > gpurun_out/bench_h14_$prec.log 2>&1
       done
       timeout 400 python bench.py --model ViT-L-16 --image-size 84 --steps 3 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 > gpurun_out/bench_l16_84.log 2>&1 ;;
+    cfg4)
+      # BASELINE configs[3] at its own per-GPU batch: ViT-H/14 @ 224, fp8, 8192 pairs per GPU as 4 micro-batches (accum_freq feature cache)
+      timeout 700 python bench.py --model ViT-H-14 --batch 8192 --accum-freq 4 --precision fp8 --steps 2 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 > gpurun_out/bench_h14_B8192_accum4_fp8.log 2>&1; echo "rc=$?" >> gpurun_out/bench_h14_B8192_accum4_fp8.log ;;
+    driverbench)
+      timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_driver_form.log 2>&1; echo "rc=$?" >> gpurun_out/bench_driver_form.log ;;
     smoke)
       timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "rc=$?" >> gpurun_out/smoke.log ;;
     stats)
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof" -o r04 -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 > "$R/gpurun_out/bench_prof.log" 2>&1)
+      tail -3 gpurun_out/bench_prof.log | cut -c1-400
       db=$(find gpurun_out/prof -name '*.db' | head -1)
       [ -n "$db" ] && python tools/rocpd_stats.py "$db" > gpurun_out/kernel_stats.csv 2>&1 ;;
     pmcbench)
