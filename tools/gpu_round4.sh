@@ -56,7 +56,8 @@ for s in $STAGES; do
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof" -o r04 -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 > "$R/gpurun_out/bench_prof.log" 2>&1)
       tail -3 gpurun_out/bench_prof.log | cut -c1-400
       db=$(find gpurun_out/prof -name '*.db' | head -1)
-      [ -n "$db" ] && python tools/rocpd_stats.py "$db" > gpurun_out/kernel_stats.csv 2>&1 ;;
+      [ -n "$db" ] && python tools/rocpd_stats.py "$db" > gpurun_out/kernel_stats.csv 2>&1
+      rm -rf gpurun_out/prof ;;      # (only <= 64 MiB of gpurun_out/ travel back: the summaries, not the databases)
     pmcbench)
       # one bench step per counter set, each in its own rocprofv3 pass (MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE never share a
       # pass; no tracing domains next to --pmc): traffic, MFMA busy + wait states + effective clock, LDS conflicts, L2 hit rate
@@ -70,7 +71,8 @@ for s in $STAGES; do
            python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 --keep-blocks ${PMC_KEEP:-0,0,24,4} > "$R/gpurun_out/pmcbench/$set.log" 2>&1)
         tail -2 "$R/gpurun_out/pmcbench/$set.log" | cut -c1-300
       done
-      python tools/pmc_summary.py gpurun_out/pmcbench gemm attn ln_ > gpurun_out/pmcbench_summary.txt 2>&1 ;;
+      python tools/pmc_summary.py gpurun_out/pmcbench gemm attn ln_ > gpurun_out/pmcbench_summary.txt 2>&1
+      find gpurun_out/pmcbench -name '*.db' -delete ;;
     *) echo "unknown stage $s" ;;
   esac
 done
