@@ -39,7 +39,7 @@ def main():
         "kernel_source_sha16": kernel_source_sha16(),
         "measured": note,
         "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, counters only; tools/gpu_round4.sh stage pmcbench) over "
-                  "`python bench.py --steps 1 --warmup 0 --keep-blocks 0,0,24,4`, dispatch-weighted mean over the %d gemm_nta_kernel dispatches of the "
+                  "`python bench.py --steps 1 --warmup 0 --keep-blocks <the plan named under 'measured'>`, dispatch-weighted mean over the %d gemm_nta_kernel dispatches of the "
                   "step; read side doubled per MI355X_MICROARCH.md (FETCH_SIZE reports 1/2 of wide coalesced reads on gfx950), WRITE_SIZE taken as "
                   "is.  Fabric-side counters: Infinity-Cache hits are included; the excess over the algorithmic bytes is operand panels re-fetched "
                   "through the fabric by each XCD's 4 MiB L2, not HBM traffic." % n,
