@@ -482,7 +482,11 @@ def main():
         if os.path.exists(tpath) and dom == "gemm_nt":
             try:
                 tj = json.load(open(tpath))
-                if tj.get("kernel_source_sha16") == kernel_source_sha16():
+                wl = tj.get("workload")
+                mine = {"model": args.model, "image_size": args.image_size, "ctx": args.ctx, "batch": B, "precision": args.precision}
+                if wl is not None and wl != mine:
+                    traffic_source = f"profiles/traffic.json was measured on {wl}, not on this workload"
+                elif tj.get("kernel_source_sha16") == kernel_source_sha16():
                     traffic = tj.get("gemm_nt_hbm_bytes_per_launch")
                     traffic_source = f"profiles/traffic.json ({tj.get('measured', 'PMC passes')}; kernel sources {tj.get('kernel_source_sha16')})"
                 else:
