@@ -163,6 +163,12 @@ def main():
                     help="share of the free HBM 'auto' may spend (default 0.95 single process, 0.90 with several ranks; a trial step + vote backs the plan off)")
     ap.add_argument("--no-light8", action="store_true",
                     help="upgrade medium-kept blocks to the bf16 'light' tier instead of 'light8' (e4m3 pre-activations)")
+    ap.add_argument("--unpad-text", action="store_true",
+                    help="run the TIMED region with the engine's unpad_text knob (causal text tower on the tokens up to each caption's "
+                         "EOT only; identical features / loss / gradients).  Off by default: `value` is measured on the reference's "
+                         "schedule (all 77 positions); the unpadded rate is reported next to it as `unpadded_text`")
+    ap.add_argument("--unpad-steps", type=int, default=3,
+                    help="extra steps after the timed region with unpad_text on (reported as `unpadded_text`, never part of `value`; 0 = skip)")
     ap.add_argument("--alloc-conf", default=None,
                     help="PyTorch caching-allocator settings applied before the first allocation, e.g. expandable_segments:True")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -220,6 +226,7 @@ def main():
     if args.ctx != model.positional_embedding.shape[0]:
         model.positional_embedding = torch.nn.Parameter(model.positional_embedding[:args.ctx].clone())
     model.set_grad_checkpointing(True)                         # every reference GPU script passes --grad-checkpointing
+    model.unpad_text = bool(args.unpad_text)
     named = list(model.named_parameters())
     exclude = lambda n, p: p.ndim < 2 or "bn" in n or "ln" in n or "bias" in n or "logit_scale" in n   # main.py:311-316
     groups = [{"params": [p for n, p in named if exclude(n, p) and p.requires_grad], "weight_decay": 0.},
@@ -416,6 +423,34 @@ def main():
             ep = float(tm)
         plain_ms = round(1e3 * ep / args.plain_steps, 2)
 
+    # The engine's unpad_text knob: same inputs, same features / loss / gradients, the causal text tower on the
+    # tokens up to each caption's EOT (SURVEY 8d's caption lengths ~ N(20, 8): about a quarter of the 77 positions).  Never
+    # part of `value`, which stays on the reference's schedule unless --unpad-text asks otherwise.
+    unpad = None
+    if args.unpad_steps > 0 and not args.unpad_text and A == 1:
+        model.unpad_text = True
+        try:
+            step()                                                           # warm-up (allocator, index structures)
+            fence()
+            tu = time.perf_counter()
+            for _ in range(args.unpad_steps):
+                loss_u = step()
+            fence()
+            eu = time.perf_counter() - tu
+            if dist_on:
+                tm = torch.tensor([eu], device=dev, dtype=torch.float64)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                eu = float(tm)
+            lens = (texts.argmax(-1) + 1).float()
+            unpad = {"value": round(B * world * args.unpad_steps / eu, 2), "unit": "pairs/s", "ms_per_step": round(1e3 * eu / args.unpad_steps, 2),
+                     "steps": args.unpad_steps, "loss": round(float(loss_u), 4),
+                     "text_positions_processed": round(float(lens.sum()) / (B * args.ctx), 4),
+                     "note": "model.unpad_text = True: the causal text tower runs on the tokens up to each caption's EOT, packed; features, "
+                             "loss and gradients are those of the padded step (tests/test_model_gpu.py::test_unpadded_text_tower_changes_nothing)"}
+        except (RuntimeError, torch.OutOfMemoryError) as e:
+            unpad = {"value": None, "error": str(e)[:200]}
+        model.unpad_text = False
+
     # PCIe-inclusive rate (the reference's batch_time includes the H2D copy, train.py:187-189): the same step
     # fed from pinned host memory with staged uint8 NHWC images through DevicePrefetcher (copy stream, double buffered) +
     # the on-device RandomResizedCrop / ColorJitter / Grayscale of the reference GPU recipe (scripts/exp/gpu/vit_l16/i37_t8_pretrain.sh:13).
@@ -501,7 +536,7 @@ def main():
             "dtype": "fp8" if args.precision == "fp8" else "bf16", "data": "synthetic",
             "config": {"workload": f"{args.model}@{args.image_size} + text-{args.ctx}, local batch {B}, "
                                    f"global batch {B * world}, " + (f"accum_freq {A} (feature cache: +1 forward per pair), " if A > 1 else "") +
-                                   f"InfoNCE local_loss+gather_with_grad, AdamW, "
+                                   f"InfoNCE local_loss+gather_with_grad, AdamW, " + ("text tower on the tokens up to EOT (unpad_text), " if args.unpad_text else "") +
                                    f"block recompute except {int(keep_v)}+{int(keep_t)} {'light8' if use_l8 else 'light'}-kept and {int(med_v)}+{int(med_t)} medium-kept (image+text) blocks", "precision": args.precision, "parallelism": f"dp{world}" + ("" if args.optimizer == "adamw" else f" zero1/{args.exchange}"),
                        "global_batch": B * world, "train_gflop_per_pair": round(gf, 2)},
             "model_flops_util": round(pairs_s / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4),
@@ -520,6 +555,7 @@ def main():
                          "launches": nt["launches"],
                          "avg_launch_ms": round(nt["ms"] / max(nt["launches"], 1), 4)},
             "h2d_inclusive": h2d,
+            "unpadded_text": unpad,
             "kernels": {k: kernel_entry(v, args.steps) for k, v in prof.items() if "|" not in k},
         }
         if args.shapes:

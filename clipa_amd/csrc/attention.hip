@@ -31,6 +31,9 @@ struct AttnArgs {
   int B, H, L;
   float scale;
   int causal;
+  // packed variable-length sequences (short kernels only; clipa_attention_*_varlen): sequence i of this launch is
+  // seq_ids[i] (or i), its rows are [seq_start[s], seq_start[s] + seq_len[s]) of the token matrix, B = sequences of the launch
+  const int* seq_start; const int* seq_len; const int* seq_ids;
 };
 
 // Geometry per head dim.  dh = 64 (ViT-S/B/L, every text tower): 128-byte LDS rows, 4 k-steps, 2 output tiles.
@@ -258,8 +261,22 @@ __host__ __device__ constexpr bool bwd_stages() {
   return (DH == 64 || DH == 80) && (WGHeads<NKT>::HPW * (2 * NKT * 32 * HD<DH>::RB + 3 * NKT * 32 * 4) + attn_waves<NKT, DH>() * Stg<DH>::BYTES) * HD<DH>::WGS <= 160 * 1024;
 }
 
+// Where the (batch, head) pair of this workgroup slot lives: fixed-length batches have sequence b at rows b * L; packed
+// variable-length launches (the text tower on the tokens up to each caption's EOT) look the sequence up.  `p` is the kernel's
+// view of the arguments with L = THIS sequence's length; statistics sit at [row0 * H + h * L + query].
+#define ATTN_LOCATE_SEQUENCE                                                     \
+  AttnArgs p = pin;                                                              \
+  long row0 = (long)b * pin.L;                                                   \
+  size_t stat0 = (size_t)head * pin.L;                                           \
+  if (pin.seq_len) {                                                             \
+    const int sid = pin.seq_ids ? pin.seq_ids[b] : b;                            \
+    p.L = pin.seq_len[sid];                                                      \
+    row0 = pin.seq_start[sid];                                                   \
+    stat0 = (size_t)row0 * pin.H + (size_t)h * p.L;                              \
+  }
+
 template <int NKT, int DH, bool CAUSAL>
-__global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void attn_fwd_kernel(AttnArgs pin) {
   constexpr int LP = NKT * 32, RB = HD<DH>::RB, KS = HD<DH>::KS, DT = HD<DH>::DT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HPW = WGHeads<NKT>::HPW, WPH = attn_waves<NKT, DH>() / HPW;
@@ -271,12 +288,13 @@ __global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void att
   constexpr bool STAGE = fwd_stages<NKT, DH>();                  // whole-row stores through 4 KB of LDS per wave
   char* stage = smem + HPW * (2 * LP * RB) + wave_wg * Stg<DH>::BYTES;
   const int l31 = lane & 31, hi = lane >> 5, q16 = (lane >> 4) & 1, i16 = lane & 15;
-  const long nheads = (long)p.B * p.H;
+  const long nheads = (long)pin.B * pin.H;
   const long head_raw = (long)blockIdx.x * HPW + slot;
   const bool live = head_raw < nheads;                           // the last workgroup may have empty head slots
   const long head = live ? head_raw : nheads - 1;
-  const int b = (int)(head / p.H), h = (int)(head - (long)b * p.H);
-  const size_t hoff = ((size_t)b * p.L * p.ld_qkv + (size_t)h * DH) * 2;
+  const int b = (int)(head / pin.H), h = (int)(head - (long)b * pin.H);
+  ATTN_LOCATE_SEQUENCE
+  const size_t hoff = ((size_t)row0 * p.ld_qkv + (size_t)h * DH) * 2;
   const unsigned nrec = (unsigned)((long)(p.L - 1) * p.ld_qkv * 2 + DH * 2);
   const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.q + hoff, nrec);
   const __amdgpu_buffer_rsrc_t rsK = make_rsrc(p.k + hoff, nrec);
@@ -336,13 +354,13 @@ __global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void att
       }
     }
     if constexpr (STAGE) {
-      if (live) store_tile<DH>(stage, p.o, p.ld_o, (long)b * p.L + 32 * qt, p.L - 32 * qt, h * DH, lane, o, inv);
-      if (qg < p.L && live && p.stats && hi == 0) *(float2*)(p.stats + ((size_t)head * p.L + qg) * 2) = make_float2(m2, inv);
+      if (live) store_tile<DH>(stage, p.o, p.ld_o, row0 + 32 * qt, p.L - 32 * qt, h * DH, lane, o, inv);
+      if (qg < p.L && live && p.stats && hi == 0) *(float2*)(p.stats + (stat0 + qg) * 2) = make_float2(m2, inv);
     } else if (qg < p.L && live) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
-        store_frag_T(p.o, p.ld_o, (long)b * p.L + qg, h * DH + 32 * dt, hi, o[dt], inv, DH - 32 * dt);
-      if (p.stats && hi == 0) *(float2*)(p.stats + ((size_t)head * p.L + qg) * 2) = make_float2(m2, inv);
+        store_frag_T(p.o, p.ld_o, row0 + qg, h * DH + 32 * dt, hi, o[dt], inv, DH - 32 * dt);
+      if (p.stats && hi == 0) *(float2*)(p.stats + (stat0 + qg) * 2) = make_float2(m2, inv);
     }
   }
 }
@@ -355,7 +373,7 @@ __global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void att
 // arithmetic, bit-identical results - measured 2-14 % SLOWER on every production shape and was dropped:
 // profiles/r02_attention_bwd_pipelining_ab.jsonl.  The kernel moves ~13 GB per launch; it is not issue-bound.)
 template <int NKT, int DH, bool CAUSAL>
-__global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void attn_bwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void attn_bwd_kernel(AttnArgs pin) {
   constexpr int LP = NKT * 32, RB = HD<DH>::RB, KS = HD<DH>::KS, DT = HD<DH>::DT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HPW = WGHeads<NKT>::HPW, WPH = attn_waves<NKT, DH>() / HPW;
@@ -375,20 +393,21 @@ __global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void att
   constexpr bool STAGE = bwd_stages<NKT, DH>();                  // whole-row stores through 4 KB of LDS per wave
   char* stage = smem + HPW * (2 * LP * RB + 3 * LP * 4) + wave_wg * Stg<DH>::BYTES;
   const int l31 = lane & 31, hi = lane >> 5, q16 = (lane >> 4) & 1, i16 = lane & 15;
-  const long nheads = (long)p.B * p.H;
+  const long nheads = (long)pin.B * pin.H;
   const long head_raw = (long)blockIdx.x * HPW + slot;
   const bool live = head_raw < nheads;
   const long head = live ? head_raw : nheads - 1;
-  const int b = (int)(head / p.H), h = (int)(head - (long)b * p.H);
-  const size_t hoff = ((size_t)b * p.L * p.ld_qkv + (size_t)h * DH) * 2;
-  const size_t ooff = ((size_t)b * p.L * p.ld_o + (size_t)h * DH) * 2;
+  const int b = (int)(head / pin.H), h = (int)(head - (long)b * pin.H);
+  ATTN_LOCATE_SEQUENCE
+  const size_t hoff = ((size_t)row0 * p.ld_qkv + (size_t)h * DH) * 2;
+  const size_t ooff = ((size_t)row0 * p.ld_o + (size_t)h * DH) * 2;
   const unsigned nrec = (unsigned)((long)(p.L - 1) * p.ld_qkv * 2 + DH * 2);
   const unsigned nrec_o = (unsigned)((long)(p.L - 1) * p.ld_o * 2 + DH * 2);
   const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.q + hoff, nrec), rsK = make_rsrc(p.k + hoff, nrec),
                                rsV = make_rsrc(p.v + hoff, nrec), rsDO = make_rsrc(p.d_o + ooff, nrec_o),
                                rsO = make_rsrc(p.o_in + ooff, nrec_o);
   const float c = p.scale * 1.4426950408889634f;
-  const float* stats = p.stats + (size_t)head * p.L * 2;
+  const float* stats = p.stats + stat0 * 2;
 
   // ---- phase 1: dQ ------------------------------------------------------------------------------
   dma_image<DH>(rsK, img0, LP, p.ld_qkv, wave, lane, WPH);
@@ -455,11 +474,11 @@ __global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void att
       }
     }
     if constexpr (STAGE) {
-      if (live) store_tile<DH>(stage, p.dq, p.ld_dqkv, (long)b * p.L + 32 * qt, p.L - 32 * qt, h * DH, lane, dq, 1.0f);
+      if (live) store_tile<DH>(stage, p.dq, p.ld_dqkv, row0 + 32 * qt, p.L - 32 * qt, h * DH, lane, dq, 1.0f);
     } else if (qg < p.L && live) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
-        store_frag_T(p.dq, p.ld_dqkv, (long)b * p.L + qg, h * DH + 32 * dt, hi, dq[dt], 1.0f, DH - 32 * dt);
+        store_frag_T(p.dq, p.ld_dqkv, row0 + qg, h * DH + 32 * dt, hi, dq[dt], 1.0f, DH - 32 * dt);
     }
   }
   // the wave's first key tile of phase 2 is still in the K / V images: same register layout as the row-wise global load, which
@@ -536,14 +555,14 @@ __global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void att
     }
     if constexpr (STAGE) {
       if (live) {
-        store_tile<DH>(stage, p.dk, p.ld_dqkv, (long)b * p.L + 32 * kt, p.L - 32 * kt, h * DH, lane, dk, 1.0f);
-        store_tile<DH>(stage, p.dv, p.ld_dqkv, (long)b * p.L + 32 * kt, p.L - 32 * kt, h * DH, lane, dv, 1.0f);
+        store_tile<DH>(stage, p.dk, p.ld_dqkv, row0 + 32 * kt, p.L - 32 * kt, h * DH, lane, dk, 1.0f);
+        store_tile<DH>(stage, p.dv, p.ld_dqkv, row0 + 32 * kt, p.L - 32 * kt, h * DH, lane, dv, 1.0f);
       }
     } else if (kg < p.L && live) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        store_frag_T(p.dk, p.ld_dqkv, (long)b * p.L + kg, h * DH + 32 * dt, hi, dk[dt], 1.0f, DH - 32 * dt);
-        store_frag_T(p.dv, p.ld_dqkv, (long)b * p.L + kg, h * DH + 32 * dt, hi, dv[dt], 1.0f, DH - 32 * dt);
+        store_frag_T(p.dk, p.ld_dqkv, row0 + kg, h * DH + 32 * dt, hi, dk[dt], 1.0f, DH - 32 * dt);
+        store_frag_T(p.dv, p.ld_dqkv, row0 + kg, h * DH + 32 * dt, hi, dv[dt], 1.0f, DH - 32 * dt);
       }
     }
   }
@@ -989,6 +1008,56 @@ extern "C" int clipa_attention_bwd(const void* q, const void* k, const void* v, 
   a.stats = const_cast<float*>(stats);
   if (wide_head(dh)) return clipa_attn_wide_launch(&a, dh, 1, stream);
   if (L > 288) return dispatch_long<true>(a, dh, (hipStream_t)stream);
+  ATTN_DISPATCH(launch_bwd, dh, a, (hipStream_t)stream)
+}
+// ---- packed variable-length sequences -------------------------------------------------------------------------------------
+// The text tower's captions end at their EOT token; under the causal mask no later position can reach the pooled output
+// (model.py:251-254: x[arange, text.argmax(-1)]) or receive gradient, so the engine may run the tower on the tokens up to EOT
+// only, packed back to back in one [T, 3D] matrix.  One launch handles the `nseq` sequences listed in seq_ids (or all of
+// 0 .. nseq-1) whose lengths are <= 32 * tiles; seq_start / seq_len are indexed by sequence id.  Statistics: [T, H] pairs laid
+// out per sequence as [H][len].  Head dims 64 / 80, tiles <= 9.
+namespace {
+int varlen_args(const int* seq_start, const int* seq_len, int64_t nseq, int64_t tiles, int64_t dh) {
+  if (!seq_start || !seq_len) { clipa_set_error("attention (varlen): seq_start / seq_len missing"); return CLIPA_ERR_ARG; }
+  if (tiles < 1 || tiles > 9) { clipa_set_error("attention (varlen): tiles=%ld outside [1, 9] (sequences of up to 288 tokens)", (long)tiles); return CLIPA_ERR_ARG; }
+  if (dh != 64 && dh != 80) { clipa_set_error("attention (varlen): head dim %ld unsupported (64 and 80)", (long)dh); return CLIPA_ERR_ARG; }
+  (void)nseq;
+  return 0;
+}
+}  // namespace
+
+extern "C" int clipa_attention_fwd_varlen(const void* q, const void* k, const void* v, void* out, float* stats,
+                                          const int32_t* seq_start, const int32_t* seq_len, const int32_t* seq_ids, int64_t nseq,
+                                          int64_t tiles, int64_t H, int64_t dh, int64_t ld_qkv, int64_t ld_o, float scale,
+                                          int causal, void* stream) {
+  if (nseq * H == 0) return CLIPA_OK;
+  if (int rc = check_args(nseq, H, 32 * tiles, dh, ld_qkv, ld_o, causal)) return rc;
+  if (int rc = varlen_args(seq_start, seq_len, nseq, tiles, dh)) return rc;
+  AttnArgs a = {};
+  a.q = (const char*)q; a.k = (const char*)k; a.v = (const char*)v; a.ld_qkv = ld_qkv;
+  a.o = (char*)out; a.ld_o = ld_o; a.B = (int)nseq; a.H = (int)H; a.L = (int)(32 * tiles); a.scale = scale; a.causal = causal;
+  a.stats = stats;
+  a.seq_start = seq_start; a.seq_len = seq_len; a.seq_ids = seq_ids;
+  ATTN_DISPATCH(launch_fwd, dh, a, (hipStream_t)stream)
+}
+
+extern "C" int clipa_attention_bwd_varlen(const void* q, const void* k, const void* v, const void* out, const void* d_out,
+                                          const float* stats, void* dq, void* dk, void* dv, const int32_t* seq_start,
+                                          const int32_t* seq_len, const int32_t* seq_ids, int64_t nseq, int64_t tiles, int64_t H,
+                                          int64_t dh, int64_t ld_qkv, int64_t ld_o, int64_t ld_dqkv, float scale, int causal,
+                                          void* stream) {
+  if (nseq * H == 0) return CLIPA_OK;
+  if (int rc = check_args(nseq, H, 32 * tiles, dh, ld_qkv, ld_o, causal)) return rc;
+  if (int rc = varlen_args(seq_start, seq_len, nseq, tiles, dh)) return rc;
+  if (ld_dqkv % 8 != 0) { clipa_set_error("attention_bwd (varlen): ld_dqkv must be a multiple of 8"); return CLIPA_ERR_ARG; }
+  if (!stats) { clipa_set_error("attention_bwd (varlen): needs the forward's softmax statistics"); return CLIPA_ERR_ARG; }
+  AttnArgs a = {};
+  a.q = (const char*)q; a.k = (const char*)k; a.v = (const char*)v; a.ld_qkv = ld_qkv;
+  a.o_in = (const char*)out; a.d_o = (const char*)d_out; a.ld_o = ld_o;
+  a.dq = (char*)dq; a.dk = (char*)dk; a.dv = (char*)dv; a.ld_dqkv = ld_dqkv;
+  a.B = (int)nseq; a.H = (int)H; a.L = (int)(32 * tiles); a.scale = scale; a.causal = causal;
+  a.stats = const_cast<float*>(stats);
+  a.seq_start = seq_start; a.seq_len = seq_len; a.seq_ids = seq_ids;
   ATTN_DISPATCH(launch_bwd, dh, a, (hipStream_t)stream)
 }
 #endif   // CLIPA_ATTN_WIDE

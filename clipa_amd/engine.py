@@ -63,6 +63,23 @@ def _like_param(g, p):
 
 
 # ---------------------------------------------------------------------------------------------
+def _attn_fwd(qkv, cfg, want_stats):
+    """-> (attention output, softmax statistics | None); fixed-length batches or packed variable-length sequences."""
+    vl = cfg.get("varlen")
+    if vl is not None:
+        r = ops.attention_fwd_varlen(qkv, vl, cfg["H"], cfg["causal"], want_stats=want_stats)
+    else:
+        r = ops.attention_fwd(qkv, cfg["B"], cfg["L"], cfg["H"], cfg["causal"], want_stats=want_stats)
+    return r if want_stats else (r, None)
+
+
+def _attn_bwd(qkv, a, da, stats, cfg):
+    vl = cfg.get("varlen")
+    if vl is not None:
+        return ops.attention_bwd_varlen(qkv, a, da, stats, vl, cfg["H"], cfg["causal"])
+    return ops.attention_bwd(qkv, a, da, stats, cfg["B"], cfg["L"], cfg["H"], cfg["causal"])
+
+
 def _block_forward(x, P, cfg, keep):
     """x [M,D] bf16. P: dict of operand tensors. Returns y and (if keep) the intermediates.
     keep: False (nothing), True / "full" (everything the backward reads), "light" (only the GEMM / attention
@@ -77,10 +94,7 @@ def _block_forward(x, P, cfg, keep):
         return _block_forward_fp8(x, P, cfg, keep)
     h1 = ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"])
     qkv = ops.gemm_nt(h1, P["w_in"], P["b_in"])
-    if keep:
-        a, stats = ops.attention_fwd(qkv, B, L, H, causal, want_stats=True)
-    else:
-        a, stats = ops.attention_fwd(qkv, B, L, H, causal), None
+    a, stats = _attn_fwd(qkv, cfg, bool(keep))
     x1 = ops.gemm_nt(a, P["w_out"], P["b_out"], epi=ops.EPI_ADD, aux=x)
     h2 = ops.layernorm_fwd(x1, P["ln2_w"], P["ln2_b"], cfg["eps"])
     if keep and keep != "medium":
@@ -121,10 +135,7 @@ def _block_forward_fp8(x, P, cfg, keep):
     h1, q1, s1 = ops.layernorm_fwd_q8(x, P["ln1_w"], P["ln1_b"], cfg["eps"], want_bf16=full)
     qkv = _lin8(q1, s1, P, "in")
     del q1, s1
-    if keep:
-        a, stats = ops.attention_fwd(qkv, B, L, H, causal, want_stats=True)
-    else:
-        a, stats = ops.attention_fwd(qkv, B, L, H, causal), None
+    a, stats = _attn_fwd(qkv, cfg, bool(keep))
     qa, sa = ops.quantize_rows(a)
     x1 = _lin8(qa, sa, P, "out", epi=ops.EPI_ADD, aux=x)
     del qa, sa
@@ -175,7 +186,7 @@ def _block_backward(x, dy, box, P, cfg):
     # x1 = x + out_proj(a)
     da = _dlin8(dx1, P, "out", cfg) if fp8 else ops.gemm_nt(dx1, P["wt_out"])
     d_w_out, d_b_out = ops.gemm_tn(dx1, a, P["dt_w_out"], want_colsum=True)
-    dqkv = ops.attention_bwd(qkv, a, da, stats, B, L, H, causal)
+    dqkv = _attn_bwd(qkv, a, da, stats, cfg)
     del da, a, qkv, stats
     dh1 = _dlin8(dqkv, P, "in", cfg) if fp8 else ops.gemm_nt(dqkv, P["wt_in"])
     if h1 is None:

@@ -29,6 +29,9 @@ SIGNATURES = {
     "clipa_layernorm_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _F, _I32, _I32, _P, _I64, _P]),
     "clipa_attention_fwd": (_I32, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I32, _P]),
     "clipa_attention_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I32, _P]),
+    "clipa_attention_fwd_varlen": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I32, _P]),
+    "clipa_attention_bwd_varlen": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64,
+                                          _I64, _F, _I32, _P]),
     "clipa_patchify": (_I32, [_P, _P, _I64, _I64, _I64, _I64, _I32, _I32, _I32, _c.POINTER(_F), _c.POINTER(_F), _P]),
     "clipa_resized_crop_workspace": (_I64, [_I64, _I64, _I64]),
     "clipa_resized_crop_u8": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _I64, _P, _P]),

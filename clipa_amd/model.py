@@ -163,12 +163,12 @@ class Transformer(nn.Module):
     def get_cast_dtype(self):
         return self.resblocks[0].mlp.c_fc.weight.dtype
 
-    def run(self, x, B, L, causal, cache):
+    def run(self, x, B, L, causal, cache, varlen=None):
         if causal and self.width // self.heads > 80:
             _unsupported(f"causal attention with head dim {self.width // self.heads} (the wide heads are compiled for image towers)")
         base = {"B": B, "L": L, "H": self.heads, "causal": bool(causal), "act": self.act, "eps": 1e-5,
                 "recompute": bool(self.grad_checkpointing), "keep": "light", "fp8": bool(self.fp8),
-                "fp8_grad_fmt": ops.FMT_E5M2 if self.fp8_grad_format == "e5m2" else ops.FMT_E4M3}
+                "fp8_grad_fmt": ops.FMT_E5M2 if self.fp8_grad_format == "e5m2" else ops.FMT_E4M3, "varlen": varlen}
         kept, medium = dict(base, keep_this=True), dict(base, keep_this=True, keep="medium")
         light8 = dict(base, keep_this=True, keep="light8")
         n1, n2 = self.keep_blocks, self.keep_blocks + self.light8_blocks
@@ -315,6 +315,7 @@ class CLIP(nn.Module):
             _unsupported("HF text towers / embed_cls")
         self._cache = engine.WeightCache()
         self._gather_partner = None          # weakref to a ClipLoss that opted in with loss.bind(model)
+        self.unpad_text = False              # engine knob: run the causal text tower on the tokens up to each caption's EOT only
         self.visual = VisionTransformer(
             image_size=vision_cfg.image_size, patch_size=vision_cfg.patch_size, width=vision_cfg.width,
             layers=vision_cfg.layers, heads=vision_cfg.width // vision_cfg.head_width, mlp_ratio=vision_cfg.mlp_ratio,
@@ -382,6 +383,20 @@ class CLIP(nn.Module):
         text = text.long()
         B, T = text.shape
         x0 = engine.TextStemFn.apply(text, self._cache, self.token_embedding.weight, self.positional_embedding)
+        if self.unpad_text and self.causal and self.pool_style == 'open_clip':
+            # MI355X engine knob (no reference counterpart, results unchanged): under the causal mask (transformer.py:618-624) no
+            # position after a caption's EOT can reach the pooled row x[arange, text.argmax(-1)] (model.py:251-254) or receive
+            # gradient, so the tower runs on the tokens up to EOT only, packed back to back (zero-padded to whole GEMM tiles).
+            # The lengths come to the host once per forward (B integers) to build the index structure.
+            eot = ops.argmax_tokens(text)
+            vl = ops.VarLen(eot.to(torch.int64).cpu() + 1, T, x0.device)
+            xp = engine.TokenDropFn.apply(x0, vl.src_rows)
+            xL = self.transformer.run(xp, B, T, True, self._cache, varlen=vl)
+            pooled = engine.TokenDropFn.apply(xL, vl.last_rows)
+            hcfg = {"B": B, "L": 1, "mode": ops.POOL_FIRST, "eps": 1e-5}
+            features = engine.HeadFn.apply(pooled, None, hcfg, self._cache, self.ln_final.weight, self.ln_final.bias,
+                                           self.text_projection)
+            return engine.L2NormFn.apply(features) if normalize else features
         xL = self.transformer.run(x0, B, T, self.causal, self._cache)
         if self.pool_style == 'open_clip':
             mode, idx = ops.POOL_INDEX, ops.argmax_tokens(text)

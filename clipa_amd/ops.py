@@ -327,6 +327,66 @@ def attention_bwd(qkv, out, dout, stats, B, L, H, causal):
     return dqkv
 
 
+class VarLen:
+    """Packed variable-length sequences (the text tower on the tokens up to each caption's EOT): host-built index structure.
+    lens: int64 CPU tensor [B] (>= 1 each).  Sequence b occupies rows [start[b], start[b] + lens[b]) of a [rows, D] token matrix
+    whose row count is padded to a multiple of 256 (whole GEMM tiles; the pad rows are zero and belong to no sequence)."""
+
+    def __init__(self, lens, ctx, device):
+        lens = lens.to(torch.int64).cpu()
+        self.B, self.ctx = int(lens.numel()), int(ctx)
+        start = torch.cumsum(lens, 0) - lens
+        self.T = int(lens.sum())
+        self.rows = max(256, (self.T + 255) // 256 * 256)
+        self.lens_host = lens
+        put = (lambda t: t.pin_memory().to(device, non_blocking=True)) if torch.device(device).type == "cuda" else (lambda t: t)
+        self.seq_start = put(start.to(torch.int32))
+        self.seq_len = put(lens.to(torch.int32))
+        # packed row -> row of the padded [B * ctx, D] matrix (-1 = pad row: gathers zeros, receives no gradient)
+        src = torch.repeat_interleave(torch.arange(self.B) * self.ctx - start, lens) + torch.arange(self.T)
+        self.src_rows = put(torch.cat([src, torch.full((self.rows - self.T,), -1, dtype=torch.int64)]))
+        self.last_rows = put(start + lens - 1)                     # the EOT token of every sequence, in packed rows
+        tiles = (lens + 31) // 32
+        self.classes = []                                          # (32-row tiles, int32 device ids, count)
+        for k in sorted(set(tiles.tolist())):
+            ids = torch.nonzero(tiles == k).flatten().to(torch.int32)
+            self.classes.append((int(k), put(ids), int(ids.numel())))
+        self.sum_len2 = float((lens.double() ** 2).sum())          # attention work: sum of len^2
+
+
+def attention_fwd_varlen(qkv, vl, H, causal, want_stats=False):
+    """attention_fwd on packed sequences: qkv [vl.rows, 3D] -> out [vl.rows, D] (pad rows zero) (+ statistics [vl.rows * H, 2])."""
+    _chk(qkv, bf16, "qkv", 2)
+    D = qkv.shape[1] // 3
+    dh = D // H
+    out = torch.zeros((vl.rows, D), device=qkv.device, dtype=bf16)
+    stats = torch.empty((vl.rows * H, 2), device=qkv.device, dtype=f32)
+    base, ld = qkv.data_ptr(), qkv.stride(0)
+    with _Timed("attention_fwd", 4.0 * H * vl.sum_len2 * dh * (0.5 if causal else 1.0), 0.0, f"varlen{vl.B},H{H},T{vl.T},dh{dh}"):
+        for tiles, ids, n in vl.classes:
+            lib.call("clipa_attention_fwd_varlen", ctypes.c_void_p(base), ctypes.c_void_p(base + 2 * D), ctypes.c_void_p(base + 4 * D),
+                     _p(out), _p(stats), _p(vl.seq_start), _p(vl.seq_len), _p(ids), n, tiles, H, dh, ld, D, 1.0 / math.sqrt(dh),
+                     int(causal), _stream())
+    return (out, stats) if want_stats else out
+
+
+def attention_bwd_varlen(qkv, out, dout, stats, vl, H, causal):
+    _chk(qkv, bf16, "qkv", 2)
+    _chk(stats, f32, "stats", 2)
+    dout = dout.contiguous()
+    D = qkv.shape[1] // 3
+    dh = D // H
+    dqkv = torch.zeros_like(qkv)                                   # pad rows belong to no sequence: their gradient is zero
+    base, dbase = qkv.data_ptr(), dqkv.data_ptr()
+    with _Timed("attention_bwd", 10.0 * H * vl.sum_len2 * dh * (0.5 if causal else 1.0), 0.0, f"varlen{vl.B},H{H},T{vl.T},dh{dh}"):
+        for tiles, ids, n in vl.classes:
+            lib.call("clipa_attention_bwd_varlen", ctypes.c_void_p(base), ctypes.c_void_p(base + 2 * D), ctypes.c_void_p(base + 4 * D),
+                     _p(out), _p(dout), _p(stats), ctypes.c_void_p(dbase), ctypes.c_void_p(dbase + 2 * D), ctypes.c_void_p(dbase + 4 * D),
+                     _p(vl.seq_start), _p(vl.seq_len), _p(ids), n, tiles, H, dh, qkv.stride(0), D, dqkv.stride(0), 1.0 / math.sqrt(dh),
+                     int(causal), _stream())
+    return dqkv
+
+
 def patchify(img, P, Kp, mean=None, std=None):
     """img [B,3,S,S] (NCHW or channels_last memory), u8 / bf16 / f32 -> bf16 [B*(S//P)^2, Kp]."""
     if not img.is_cuda:

@@ -106,6 +106,20 @@ int clipa_attention_bwd(const void* q, const void* k, const void* v, const void*
                         const float* stats, void* dq, void* dk, void* dv, int64_t B, int64_t H, int64_t L,
                         int64_t dh, int64_t ld_qkv, int64_t ld_o, int64_t ld_dqkv, float scale, int causal,
                         void* stream);
+/* The same kernels on PACKED variable-length sequences (MI355X engine extension: the text tower on the tokens up to each
+ * caption's EOT - under the causal mask of transformer.py:618-624 no later position can reach the pooled output of
+ * model.py:251-254 or receive gradient, so features, loss and gradients are unchanged).  q / k / v / out rows are token rows of
+ * the packed matrix; sequence s occupies rows [seq_start[s], seq_start[s] + seq_len[s]).  One call processes the nseq
+ * sequences named by seq_ids (int32 device array; NULL = sequences 0 .. nseq-1), all of length <= 32 * tiles (tiles <= 9);
+ * stats: T * H (max, 1/sum) pairs.  Head dims 64 / 80. */
+int clipa_attention_fwd_varlen(const void* q, const void* k, const void* v, void* out, float* stats,
+                               const int32_t* seq_start, const int32_t* seq_len, const int32_t* seq_ids, int64_t nseq,
+                               int64_t tiles, int64_t H, int64_t dh, int64_t ld_qkv, int64_t ld_o, float scale, int causal,
+                               void* stream);
+int clipa_attention_bwd_varlen(const void* q, const void* k, const void* v, const void* out, const void* d_out,
+                               const float* stats, void* dq, void* dk, void* dv, const int32_t* seq_start,
+                               const int32_t* seq_len, const int32_t* seq_ids, int64_t nseq, int64_t tiles, int64_t H, int64_t dh,
+                               int64_t ld_qkv, int64_t ld_o, int64_t ld_dqkv, float scale, int causal, void* stream);
 
 /* image [B,3,S,S] (or NHWC) u8/bf16/f32 -> bf16 patch matrix [B*(S/P)^2, Kp], elements in (ph,pw,c)
  * order, optional (x/255 - mean)/std (train.py:191-197 + conv1 im2col, transformer.py:371,491-493). */

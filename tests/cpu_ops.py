@@ -113,6 +113,42 @@ def attention_bwd(qkv, out, dout, stats, B, L, H, causal):
     return x.grad.reshape(B * L, 3 * D).to(bf16)
 
 
+class VarLen:
+    """Stand-in of clipa_amd.ops.VarLen (same fields, CPU tensors)."""
+
+    def __init__(self, lens, ctx, device):
+        lens = lens.to(torch.int64).cpu()
+        self.B, self.ctx = int(lens.numel()), int(ctx)
+        start = torch.cumsum(lens, 0) - lens
+        self.T = int(lens.sum())
+        self.rows = max(256, (self.T + 255) // 256 * 256)
+        self.lens_host, self.seq_start, self.seq_len = lens, start.to(torch.int32), lens.to(torch.int32)
+        src = torch.repeat_interleave(torch.arange(self.B) * self.ctx - start, lens) + torch.arange(self.T)
+        self.src_rows = torch.cat([src, torch.full((self.rows - self.T,), -1, dtype=torch.int64)])
+        self.last_rows = start + lens - 1
+        self.classes = []
+        self.sum_len2 = float((lens.double() ** 2).sum())
+
+
+def attention_fwd_varlen(qkv, vl, H, causal, want_stats=False):
+    D = qkv.shape[1] // 3
+    out = torch.zeros((vl.rows, D), dtype=bf16)
+    for s0, n in zip(vl.seq_start.tolist(), vl.seq_len.tolist()):
+        out[s0:s0 + n] = O.attention(qkv[s0:s0 + n].float().reshape(1, n, 3 * D), H, causal).reshape(n, D).to(bf16)
+    return (out, torch.zeros(vl.rows * H, 2)) if want_stats else out
+
+
+def attention_bwd_varlen(qkv, out, dout, stats, vl, H, causal):
+    D = qkv.shape[1] // 3
+    dq = torch.zeros_like(qkv)
+    for s0, n in zip(vl.seq_start.tolist(), vl.seq_len.tolist()):
+        x = qkv[s0:s0 + n].float().reshape(1, n, 3 * D).detach().requires_grad_(True)
+        with torch.enable_grad():
+            O.attention(x, H, causal).backward(dout[s0:s0 + n].float().reshape(1, n, D))
+        dq[s0:s0 + n] = x.grad.reshape(n, 3 * D).to(bf16)
+    return dq
+
+
 def patchify(img, P, Kp, mean=None, std=None):
     B, _, S, _ = img.shape
     g = S // P
@@ -278,10 +314,13 @@ def reduce_shards(pieces, world, out=None, scale=None, out_dtype=None):
 
 
 def gather_rows(x, rows):
-    return x[rows].contiguous()
+    out = x[rows.clamp_min(0)].contiguous()
+    out[rows < 0] = 0                       # rows outside [0, n) read zeros, as the kernel does
+    return out
 
 
 def scatter_rows(dy, rows, n_dst):
     dx = torch.zeros((n_dst, dy.shape[1]), dtype=dy.dtype)
-    dx[rows] = dy
+    ok = rows >= 0
+    dx[rows[ok]] = dy[ok]
     return dx

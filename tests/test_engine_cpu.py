@@ -104,6 +104,34 @@ def test_patch_dropout_orchestration_matches_reference_golden():
     _patch_dropout_check()
 
 
+@pytest.mark.parametrize("case", ["cls_erf", "gap_sincos_tanh", "h14_dh80"])
+def test_unpadded_text_tower_changes_nothing(case):
+    """Engine knob `unpad_text`: the causal text tower on the tokens up to each caption's EOT only (packed back to back).  Under
+    the causal mask nothing after EOT can reach the pooled row or receive gradient: features and loss are IDENTICAL to the
+    padded run, every gradient agrees to fp32 summation order."""
+    g = load_golden(case)
+    ma, oa, la = _run(g, recompute=True)
+    mb = clipa_amd.CLIP(**g.cfg, output_dict=True)
+    mb.load_state_dict(g.sd, strict=True)
+    mb.set_grad_checkpointing(True)
+    mb.unpad_text = True
+    mb.transformer.keep_blocks, mb.transformer.medium_blocks = 0, 1
+    ob = mb(g.images_u8, g.texts)
+    lb = clipa_amd.ClipLoss()(**ob, output_dict=True)["contrastive_loss"]
+    lb.backward()
+    lens = g.texts.argmax(-1) + 1
+    assert int(lens.min()) < g.texts.shape[1], "the fixture must contain padded captions for this test to mean anything"
+    assert torch.equal(oa["text_features"], ob["text_features"]) and float(la) == float(lb)
+    for (k, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
+        if p.grad is None:
+            assert q.grad is None, k
+            continue
+        assert torch.allclose(p.grad.float(), q.grad.float(), rtol=2e-2, atol=1e-6), k
+        a, b = p.grad.double().reshape(-1), q.grad.double().reshape(-1)
+        if float(a.norm()) > 1e-9 and a.numel() > 1:
+            assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.99999, k
+
+
 def test_recompute_equals_stored(golden):
     ma, _, la = _run(golden, recompute=True)
     mb, _, lb = _run(golden, recompute=False)

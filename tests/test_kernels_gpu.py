@@ -370,6 +370,50 @@ def test_attention_wide_heads(dh, B, H, L):
         ops().attention_fwd(qkv.to(DEV), B, L, H, True)
 
 
+@pytest.mark.parametrize("dh,H,ctx,causal", [(64, 3, 77, True), (64, 2, 32, True), (80, 2, 77, True), (64, 2, 197, False)])
+def test_attention_packed_variable_length(dh, H, ctx, causal):
+    """clipa_attention_*_varlen: sequences of different lengths packed back to back (the text tower on the tokens up to EOT),
+    one launch per class of 32-row tile counts.  Every sequence against the oracle on that sequence alone, and - causal case -
+    BIT FOR BIT against the fixed-length kernels run on the zero-padded batch (what the reference computes): the rows up to
+    each sequence's end agree in the forward, and with the gradient zero beyond them, in the backward."""
+    o = ops()
+    g = torch.Generator().manual_seed(5 + ctx + dh)
+    B = 23
+    lens = torch.randint(1, ctx + 1, (B,), generator=g)
+    lens[0], lens[1], lens[2] = ctx, 1, min(ctx, 33)
+    D = dh * H
+    vl = o.VarLen(lens, ctx, DEV)
+    assert vl.rows % 256 == 0 and vl.T == int(lens.sum())
+    qkv = torch.zeros(vl.rows, 3 * D, dtype=bf16)
+    dout = torch.zeros(vl.rows, D, dtype=bf16)
+    qkv[:vl.T] = rnd(vl.T, 3 * D, seed=41, scale=1.2)
+    dout[:vl.T] = rnd(vl.T, D, seed=42)
+    qkv_d, dout_d = qkv.to(DEV), dout.to(DEV)
+    got, stats = o.attention_fwd_varlen(qkv_d, vl, H, causal, want_stats=True)
+    assert torch.equal(got, o.attention_fwd_varlen(qkv_d, vl, H, causal))
+    dq = o.attention_bwd_varlen(qkv_d, got, dout_d, stats, vl, H, causal)
+    starts = (torch.cumsum(lens, 0) - lens).tolist()
+    for b, (s0, n) in enumerate(zip(starts, lens.tolist())):
+        x = qkv[s0:s0 + n].double().reshape(1, n, 3 * D).requires_grad_(True)
+        ref = O.attention(x, H, causal)
+        ref.backward(dout[s0:s0 + n].double().reshape(1, n, D))
+        check(f"fwd seq {b} (len {n})", got[s0:s0 + n].reshape(1, n, D), ref, 2 ** -6, 8e-3)
+        check(f"dqkv seq {b} (len {n})", dq[s0:s0 + n].reshape(1, n, 3 * D), x.grad, 2 ** -5, 2e-2)
+    assert float(got[vl.T:].float().abs().max() if vl.rows > vl.T else 0) == 0 and float(dq[vl.T:].float().abs().max() if vl.rows > vl.T else 0) == 0
+    if causal:
+        pad_qkv = torch.zeros(B * ctx, 3 * D, dtype=bf16)
+        pad_dout = torch.zeros(B * ctx, D, dtype=bf16)
+        for b, (s0, n) in enumerate(zip(starts, lens.tolist())):
+            pad_qkv[b * ctx:b * ctx + n] = qkv[s0:s0 + n]
+            pad_dout[b * ctx:b * ctx + n] = dout[s0:s0 + n]
+        pq, pd = pad_qkv.to(DEV), pad_dout.to(DEV)
+        pout, pstats = o.attention_fwd(pq, B, ctx, H, True, want_stats=True)
+        pdq = o.attention_bwd(pq, pout, pd, pstats, B, ctx, H, True)
+        for b, (s0, n) in enumerate(zip(starts, lens.tolist())):
+            assert torch.equal(pout[b * ctx:b * ctx + n], got[s0:s0 + n]), (b, n)
+            assert torch.equal(pdq[b * ctx:b * ctx + n], dq[s0:s0 + n]), (b, n)
+
+
 @pytest.mark.parametrize("dh", [64, 80])
 @pytest.mark.parametrize("B,H,L,causal", [(2, 2, 577, False), (1, 3, 401, False), (1, 2, 300, True), (1, 1, 1024, False)])
 def test_attention_long_sequences(B, H, L, causal, dh):

@@ -348,6 +348,32 @@ def test_light8_rounding_averages_out_over_the_batch():
     assert worst[16][0] > 0.99 and worst[1024][0] > 0.998 and (1 - worst[1024][0]) < 0.5 * (1 - worst[16][0]), worst
 
 
+@pytest.mark.parametrize("case", ["cls_erf", "full_B16_224", "full_S16_112_t32"])
+def test_unpadded_text_tower_changes_nothing(case):
+    """Engine knob `unpad_text` (the causal text tower on the tokens up to each caption's EOT, packed): text features and loss
+    are the padded run's BIT FOR BIT (every kernel is row-wise or per sequence), every gradient agrees to the summation order
+    of the weight-gradient slices (cosine >= 0.99999); toy and BASELINE dimensions, recompute and kept tiers mixed."""
+    g = load_golden(case)
+    a = _engine(g)
+    oa, la = _step(a, g)
+    b = _engine(g)
+    b.unpad_text = True
+    b.transformer.keep_blocks, b.transformer.medium_blocks = 1, 1
+    ob, lb = _step(b, g)
+    lens = g.texts.argmax(-1) + 1
+    assert int(lens.min()) < g.texts.shape[1]
+    assert torch.equal(oa["text_features"], ob["text_features"]) and torch.equal(oa["image_features"], ob["image_features"])
+    assert float(la) == float(lb)
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        if p.grad is None:
+            assert q.grad is None, k
+            continue
+        x, y = p.grad.double().reshape(-1), q.grad.double().reshape(-1)
+        if float(x.norm()) > 1e-9 and x.numel() > 1:
+            assert float(torch.dot(x, y) / (x.norm() * y.norm())) > 0.99999, k
+        assert torch.allclose(p.grad.float(), q.grad.float(), rtol=3e-2, atol=1e-5 * float(p.grad.float().abs().max()) + 1e-9), k
+
+
 def test_input_formats_agree():
     """uint8 NCHW, uint8 channels_last and pre-normalised float inputs give the same features."""
     g = load_golden("cls_erf")
