@@ -518,8 +518,8 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 wl = tj.get("workload")
-                mine = {"model": args.model, "image_size": args.image_size, "ctx": args.ctx, "batch": B, "precision": args.precision}
-                if wl is not None and wl != mine:
+                this_wl = {"model": args.model, "image_size": args.image_size, "ctx": args.ctx, "batch": B, "precision": args.precision}
+                if wl is not None and wl != this_wl:
                     traffic_source = f"profiles/traffic.json was measured on {wl}, not on this workload"
                 elif tj.get("kernel_source_sha16") == kernel_source_sha16():
                     traffic = tj.get("gemm_nt_hbm_bytes_per_launch")
