@@ -377,7 +377,15 @@ class CLIP(nn.Module):
         features = self.visual(image)
         return engine.L2NormFn.apply(features) if normalize else features
 
-    def encode_text(self, text, normalize: bool = False):
+    def _text_varlen(self, text):
+        """The index structure of the unpadded text tower (engine knob `unpad_text`), or None.  It needs the caption lengths on
+        the host (B integers): `forward` asks for them BEFORE the image tower is enqueued, so the copy waits for nothing."""
+        if not (self.unpad_text and self.causal and self.pool_style == 'open_clip'):
+            return None
+        eot = ops.argmax_tokens(text.long())
+        return ops.VarLen(eot.to(torch.int64).cpu() + 1, text.shape[1], text.device)
+
+    def encode_text(self, text, normalize: bool = False, _varlen=None):
         if text.dim() != 2 or text.shape[1] != self.positional_embedding.shape[0]:
             raise RuntimeError(f"expected token ids [B,{self.positional_embedding.shape[0]}], got {tuple(text.shape)}")
         text = text.long()
@@ -388,8 +396,7 @@ class CLIP(nn.Module):
             # position after a caption's EOT can reach the pooled row x[arange, text.argmax(-1)] (model.py:251-254) or receive
             # gradient, so the tower runs on the tokens up to EOT only, packed back to back (zero-padded to whole GEMM tiles).
             # The lengths come to the host once per forward (B integers) to build the index structure.
-            eot = ops.argmax_tokens(text)
-            vl = ops.VarLen(eot.to(torch.int64).cpu() + 1, T, x0.device)
+            vl = _varlen if _varlen is not None else self._text_varlen(text)
             xp = engine.TokenDropFn.apply(x0, vl.src_rows)
             xL = self.transformer.run(xp, B, T, True, self._cache, varlen=vl)
             pooled = engine.TokenDropFn.apply(xL, vl.last_rows)
@@ -413,6 +420,7 @@ class CLIP(nn.Module):
         # the reference trainer runs the model under torch.autocast(bfloat16) (train.py:160,203-205; precision.py:6-14):
         # every FLOP here is a HIP kernel with its own fixed operand types, so autocast is switched off for the glue
         with torch.autocast(device_type=image.device.type, enabled=False):
+            vl = self._text_varlen(text) if text.dim() == 2 else None
             image_features = self.encode_image(image, normalize=True)
             partner = self._gather_partner() if self._gather_partner is not None else None
             if partner is not None and self.training and torch.is_grad_enabled():
@@ -420,7 +428,7 @@ class CLIP(nn.Module):
                 # all-gather of the image embeddings now, on a side stream, under the text tower (north_star:
                 # "overlapped ... on a side HIP stream").  Single rank / eval / not bound: nothing happens.
                 partner.early_gather(image_features)
-            text_features = self.encode_text(text, normalize=True)
+            text_features = self.encode_text(text, normalize=True, _varlen=vl)
             logit_scale = self.logit_scale.exp()
         if self.output_dict:
             return {"image_features": image_features, "text_features": text_features, "logit_scale": logit_scale}
