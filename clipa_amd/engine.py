@@ -3,6 +3,7 @@ backward are sequences of HIP launches (clipa_amd.ops).  Mirrors, per function, 
 it stands in for (paths relative to /root/reference/clipa_torch):
 
   ResBlockFn     ResidualAttentionBlock.forward            open_clip/transformer.py:238-250
+  LastBlockFn    the same for a tower's last block when the head reads one row per sample (returns those rows only)
   VisionStemFn   conv1 + cls/pos + ln_pre                  open_clip/transformer.py:480-503
   TokenDropFn    PatchDropout (row selection)              open_clip/transformer.py:53-83,501-502
   TextStemFn     token_embedding + positional_embedding    open_clip/model.py:245-247
@@ -247,6 +248,75 @@ class ResBlockFn(torch.autograd.Function):
         dx, grads = _block_backward(x, dy, box, P, cfg)
         grads = tuple(_like_param(g, p) if p.requires_grad else None for g, p in zip(grads, params))
         return (dx, None, None) + grads
+
+
+# ---------------------------------------------------------------------------------------------
+class LastBlockFn(torch.autograd.Function):
+    """The LAST residual block of a tower whose head reads ONE row per sample (the class token of a CLS-pooled image tower,
+    transformer.py:509-529; the EOT token of the text tower, model.py:251-254): returns that row only, [B, D].
+
+    Every other row of the last block's output is dead - nothing reads it, its gradient is exactly zero - so only the keys and
+    values need all tokens: LN1, the in-projection and attention run on every row, the out-projection, LN2 and the MLP on the B
+    pooled rows (the reference computes all B * L of them and the pooling discards them; same kind of identity as taking the
+    pooled row before ln_post, SURVEY 8a identity 8).  Forward values of the pooled rows and all gradients are those of the full
+    block (zero rows add nothing to a weight gradient).  `rows`: int64 device tensor [B], row index of the pooled token of each
+    sample in x.  The token-level part (qkv, attention output, softmax statistics) is kept or recomputed like any other block's;
+    the B-row part is always kept (a few MB)."""
+
+    @staticmethod
+    def forward(ctx, x, rows, cfg, cache, *params):
+        P = _block_operands(params, cache, False)
+        needs_grad = any(ctx.needs_input_grad)
+        keep = needs_grad and (not cfg["recompute"] or cfg.get("keep_this", False))
+        qkv, a, stats = LastBlockFn._tokens(x, P, cfg, keep)
+        a_c, x_c = ops.gather_rows(a, rows), ops.gather_rows(x, rows)
+        x1 = ops.gemm_nt(a_c, P["w_out"], P["b_out"], epi=ops.EPI_ADD, aux=x_c)
+        h2 = ops.layernorm_fwd(x1, P["ln2_w"], P["ln2_b"], cfg["eps"])
+        g, hpre = ops.gemm_nt(h2, P["w_fc"], P["b_fc"], epi=ops.EPI_ACT, act=cfg["act"], want_pre=True)
+        y = ops.gemm_nt(g, P["w_proj"], P["b_proj"], epi=ops.EPI_ADD, aux=x1)
+        ctx.cfg, ctx.cache, ctx.params = cfg, cache, params
+        if needs_grad:
+            ctx.save_for_backward(x, rows)
+            ctx.tokens = (qkv, a, stats) if keep else None
+            ctx.small = (a_c, x1, h2, hpre, g)
+        return y
+
+    @staticmethod
+    def _tokens(x, P, cfg, want_stats):
+        h1 = ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"])
+        qkv = ops.gemm_nt(h1, P["w_in"], P["b_in"])
+        a, stats = _attn_fwd(qkv, cfg, bool(want_stats))
+        return qkv, a, stats
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, rows = ctx.saved_tensors
+        cfg, params = ctx.cfg, ctx.params
+        P = _block_operands(params, ctx.cache, False)
+        a_c, x1, h2, hpre, g = ctx.small
+        ctx.small = None
+        dy = dy.contiguous()
+        M = x.shape[0]
+        dh = ops.gemm_nt(dy, P["wt_proj"], epi=ops.EPI_DACT, act=cfg["act"], aux=hpre)
+        d_w_proj, d_b_proj = ops.gemm_tn(dy, g, P["dt_w_proj"], want_colsum=True)
+        dh2 = ops.gemm_nt(dh, P["wt_fc"])
+        d_w_fc, d_b_fc = ops.gemm_tn(dh, h2, P["dt_w_fc"], want_colsum=True)
+        dx1, d_ln2_w, d_ln2_b = ops.layernorm_bwd(x1, P["ln2_w"], dh2, dres=dy, eps=cfg["eps"])
+        da_c = ops.gemm_nt(dx1, P["wt_out"])
+        d_w_out, d_b_out = ops.gemm_tn(dx1, a_c, P["dt_w_out"], want_colsum=True)
+        tok, ctx.tokens = ctx.tokens, None
+        qkv, a, stats = tok if tok is not None else LastBlockFn._tokens(x, P, cfg, True)
+        dqkv = _attn_bwd(qkv, a, ops.scatter_rows(da_c, rows, M), stats, cfg)
+        del qkv, a, stats
+        dh1 = ops.gemm_nt(dqkv, P["wt_in"])
+        h1 = ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"])
+        d_w_in, d_b_in = ops.gemm_tn(dqkv, h1, P["dt_w_in"], want_colsum=True)
+        del dqkv, h1
+        # x1 = x[rows] + out_proj(a[rows]): the residual gradient reaches x at the pooled rows only
+        dx, d_ln1_w, d_ln1_b = ops.layernorm_bwd(x, P["ln1_w"], dh1, dres=ops.scatter_rows(dx1, rows, M), eps=cfg["eps"])
+        grads = (d_ln1_w, d_ln1_b, d_w_in, d_b_in, d_w_out, d_b_out, d_ln2_w, d_ln2_b, d_w_fc, d_b_fc, d_w_proj, d_b_proj)
+        grads = tuple(_like_param(gr, p) if p.requires_grad else None for gr, p in zip(grads, params))
+        return (dx, None, None, None) + grads
 
 
 # ---------------------------------------------------------------------------------------------

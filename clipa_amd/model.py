@@ -163,7 +163,9 @@ class Transformer(nn.Module):
     def get_cast_dtype(self):
         return self.resblocks[0].mlp.c_fc.weight.dtype
 
-    def run(self, x, B, L, causal, cache, varlen=None):
+    def run(self, x, B, L, causal, cache, varlen=None, pooled_rows=None):
+        """pooled_rows (int64 device [B]): the head reads only these rows of the tower's output - the last block then computes and
+        returns only them ([B, D]; engine.LastBlockFn).  bf16 engines only; the fp8 engine runs the full last block and gathers."""
         if causal and self.width // self.heads > 80:
             _unsupported(f"causal attention with head dim {self.width // self.heads} (the wide heads are compiled for image towers)")
         base = {"B": B, "L": L, "H": self.heads, "causal": bool(causal), "act": self.act, "eps": 1e-5,
@@ -172,10 +174,13 @@ class Transformer(nn.Module):
         kept, medium = dict(base, keep_this=True), dict(base, keep_this=True, keep="medium")
         light8 = dict(base, keep_this=True, keep="light8")
         n1, n2 = self.keep_blocks, self.keep_blocks + self.light8_blocks
+        last = len(self.resblocks) - 1
         for i, blk in enumerate(self.resblocks):
             cfg = kept if i < n1 else (light8 if i < n2 else (medium if i < n2 + self.medium_blocks else base))
+            if i == last and pooled_rows is not None and not self.fp8:
+                return engine.LastBlockFn.apply(x, pooled_rows, cfg, cache, *blk.param_tuple())
             x = engine.ResBlockFn.apply(x, cfg, cache, *blk.param_tuple())
-        return x
+        return x if pooled_rows is None else engine.TokenDropFn.apply(x, pooled_rows)
 
     def light_keep_bytes(self, tokens):
         """HBM bytes one kept block holds between forward and backward for `tokens` rows."""
@@ -291,6 +296,12 @@ class VisionTransformer(nn.Module):
             rows = torch.cat([torch.zeros(B, 1, dtype=torch.int64), keep + 1], dim=1) + torch.arange(B).view(B, 1) * L
             x0 = engine.TokenDropFn.apply(x0, rows.reshape(-1).to(x0.device, non_blocking=True))
             L = 1 + keep.shape[1]
+        if self._pool_mode() == ops.POOL_FIRST:
+            # the head reads the class token only: the last block computes that row alone (engine.LastBlockFn)
+            rows = torch.arange(B, device=x0.device, dtype=torch.int64) * L
+            xc = self.transformer.run(x0, B, L, False, self._cache, pooled_rows=rows)
+            hcfg = {"B": B, "L": 1, "mode": ops.POOL_FIRST, "eps": 1e-5}
+            return engine.HeadFn.apply(xc, None, hcfg, self._cache, self.ln_post.weight, self.ln_post.bias, self.proj)
         xL = self.transformer.run(x0, B, L, False, self._cache)
         hcfg = {"B": B, "L": L, "mode": self._pool_mode(), "eps": 1e-5}
         return engine.HeadFn.apply(xL, None, hcfg, self._cache, self.ln_post.weight, self.ln_post.bias, self.proj)
@@ -398,21 +409,22 @@ class CLIP(nn.Module):
             # The lengths come to the host once per forward (B integers) to build the index structure.
             vl = _varlen if _varlen is not None else self._text_varlen(text)
             xp = engine.TokenDropFn.apply(x0, vl.src_rows)
-            xL = self.transformer.run(xp, B, T, True, self._cache, varlen=vl)
-            pooled = engine.TokenDropFn.apply(xL, vl.last_rows)
+            pooled = self.transformer.run(xp, B, T, True, self._cache, varlen=vl, pooled_rows=vl.last_rows)
             hcfg = {"B": B, "L": 1, "mode": ops.POOL_FIRST, "eps": 1e-5}
             features = engine.HeadFn.apply(pooled, None, hcfg, self._cache, self.ln_final.weight, self.ln_final.bias,
                                            self.text_projection)
             return engine.L2NormFn.apply(features) if normalize else features
-        xL = self.transformer.run(x0, B, T, self.causal, self._cache)
+        # the head reads one row per caption (EOT / first / last token): the last block computes that row alone (engine.LastBlockFn)
         if self.pool_style == 'open_clip':
-            mode, idx = ops.POOL_INDEX, ops.argmax_tokens(text)
+            pos = ops.argmax_tokens(text).to(torch.int64)
         elif self.pool_style == 'big_vision_tok':
-            mode, idx = ops.POOL_FIRST, None
+            pos = torch.zeros(B, device=x0.device, dtype=torch.int64)
         else:
-            mode, idx = ops.POOL_LAST, None
-        hcfg = {"B": B, "L": T, "mode": mode, "eps": 1e-5}
-        features = engine.HeadFn.apply(xL, idx, hcfg, self._cache, self.ln_final.weight, self.ln_final.bias,
+            pos = torch.full((B,), T - 1, device=x0.device, dtype=torch.int64)
+        rows = torch.arange(B, device=x0.device, dtype=torch.int64) * T + pos
+        pooled = self.transformer.run(x0, B, T, self.causal, self._cache, pooled_rows=rows)
+        hcfg = {"B": B, "L": 1, "mode": ops.POOL_FIRST, "eps": 1e-5}
+        features = engine.HeadFn.apply(pooled, None, hcfg, self._cache, self.ln_final.weight, self.ln_final.bias,
                                        self.text_projection)
         return engine.L2NormFn.apply(features) if normalize else features
 
