@@ -81,7 +81,7 @@ def _attn_bwd(qkv, a, da, stats, cfg):
     return ops.attention_bwd(qkv, a, da, stats, cfg["B"], cfg["L"], cfg["H"], cfg["causal"])
 
 
-def _block_forward(x, P, cfg, keep):
+def _block_forward(x, P, cfg, keep, need_y=True):
     """x [M,D] bf16. P: dict of operand tensors. Returns y and (if keep) the intermediates.
     keep: False (nothing), True / "full" (everything the backward reads), "light" (only the GEMM / attention
     outputs qkv, a, stats, x1, hpre - LayerNorm outputs and the activation are re-materialised in backward),
@@ -92,7 +92,7 @@ def _block_forward(x, P, cfg, keep):
     a third of the block's forward FLOPs, and skips the other three GEMMs and attention)."""
     B, L, H, causal, act = cfg["B"], cfg["L"], cfg["H"], cfg["causal"], cfg["act"]
     if cfg.get("fp8"):
-        return _block_forward_fp8(x, P, cfg, keep)
+        return _block_forward_fp8(x, P, cfg, keep, need_y)
     h1 = ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"])
     qkv = ops.gemm_nt(h1, P["w_in"], P["b_in"])
     a, stats = _attn_fwd(qkv, cfg, bool(keep))
@@ -102,7 +102,9 @@ def _block_forward(x, P, cfg, keep):
         g, hpre = ops.gemm_nt(h2, P["w_fc"], P["b_fc"], epi=ops.EPI_ACT, act=act, want_pre="e4m3" if keep == "light8" else True)
     else:
         g, hpre = ops.gemm_nt(h2, P["w_fc"], P["b_fc"], epi=ops.EPI_ACT, act=act), None
-    y = ops.gemm_nt(g, P["w_proj"], P["b_proj"], epi=ops.EPI_ADD, aux=x1)
+    # (need_y=False: the backward-time recompute of a block wants the intermediates only - its output is the next block's input,
+    # which that block kept; the c_proj GEMM would be thrown away)
+    y = ops.gemm_nt(g, P["w_proj"], P["b_proj"], epi=ops.EPI_ADD, aux=x1) if need_y else None
     if keep in ("light", "light8", "medium"):
         return y, (None, qkv, a, stats, x1, None, hpre, None)
     if keep:
@@ -124,7 +126,7 @@ def _dlin8(dy, P, name, cfg, **kw):
     return ops.gemm_nt_f8(dq, ds, wq, ws, None, fmt_a=fmt, **kw)
 
 
-def _block_forward_fp8(x, P, cfg, keep):
+def _block_forward_fp8(x, P, cfg, keep, need_y=True):
     """_block_forward with the four linear layers on the fp8 MFMA path (BASELINE.json configs[3]): the LayerNorms emit the
     e4m3 operand of the GEMM that follows them, the attention output and the MLP activation are quantised per token by
     clipa_quantize_rows; everything between the GEMMs (residual stream, attention, softmax statistics, kept tensors) is
@@ -146,9 +148,11 @@ def _block_forward_fp8(x, P, cfg, keep):
     else:
         g, hpre = _lin8(q2, s2, P, "fc", epi=ops.EPI_ACT, act=act), None
     del q2, s2
-    qg, sg = ops.quantize_rows(g)
-    y = _lin8(qg, sg, P, "proj", epi=ops.EPI_ADD, aux=x1)
-    del qg, sg
+    y = None
+    if need_y:
+        qg, sg = ops.quantize_rows(g)
+        y = _lin8(qg, sg, P, "proj", epi=ops.EPI_ADD, aux=x1)
+        del qg, sg
     if keep in ("light", "medium"):
         return y, (None, qkv, a, stats, x1, None, hpre, None)
     if keep:
@@ -244,7 +248,7 @@ class ResBlockFn(torch.autograd.Function):
         box = [ctx.inter]
         ctx.inter = None
         if box[0] is None:
-            box[0] = _block_forward(x, P, cfg, True)[1]
+            box[0] = _block_forward(x, P, cfg, True, need_y=False)[1]
         dx, grads = _block_backward(x, dy, box, P, cfg)
         grads = tuple(_like_param(g, p) if p.requires_grad else None for g, p in zip(grads, params))
         return (dx, None, None) + grads
