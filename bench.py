@@ -427,7 +427,8 @@ def main():
     # tokens up to each caption's EOT (SURVEY 8d's caption lengths ~ N(20, 8): about a quarter of the 77 positions).  Never
     # part of `value`, which stays on the reference's schedule unless --unpad-text asks otherwise.
     unpad = None
-    if args.unpad_steps > 0 and not args.unpad_text and A == 1:
+    # (single process only: toggling the knob changes the autograd graph, which DistributedDataParallel(static_graph=True) forbids)
+    if args.unpad_steps > 0 and not args.unpad_text and A == 1 and not dist_on:
         model.unpad_text = True
         try:
             step()                                                           # warm-up (allocator, index structures)
