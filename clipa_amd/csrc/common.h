@@ -54,12 +54,18 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
 enum { ACT_GELU_ERF = 0, ACT_GELU_TANH = 1, ACT_QUICK_GELU = 2 };
 
 // erf-GELU on PAIRS of values, WITHOUT transcendentals: Phi(x) - 1/2 = erf(x / sqrt 2) / 2 is an odd function, fitted on
-// |x| <= 4.5 as x * P(x^2) (P of degree 9: max |error of x Phi(x)| 5e-5, 8e-6 for |x| < 3; beyond 4.5 the argument is clamped,
-// Phi is clamped to [0, 1] and the error stays below 1e-5 |x| - all far inside the bf16 rounding of the result, which is
-// what every caller stores), and gelu'(x) - 1/2 = erf(x / sqrt 2) / 2 + x phi(x) likewise (degree 10: 2.4e-4 at the clamp
-// edge where gelu' = 1, 1.3e-5 for |x| < 3).  Coefficients: tools/fit_gelu_poly.py.  The epilogues of the fused GEMMs are
-// VALU-bound (profiles/r03_gemm_nta_*.jsonl): ten packed FMAs per pair cost a third of the rcp + exp2 formulation they replace
-// (Abramowitz-Stegun 7.1.26, 2 quarter-rate transcendentals per element).
+// |x| <= 4.5 as x * P(x^2) (P of degree 9) and gelu'(x) - 1/2 = erf(x / sqrt 2) / 2 + x phi(x) likewise (degree 10).
+// Coefficients: tools/fit_gelu_poly.py.  Measured in fp32 (tests/test_host_cpu.py::test_gelu_polynomials):
+//   x Phi(x): |error| <= 5.4e-5 on |x| <= 4.5 (8e-6 for |x| < 3); beyond 4.5 the argument is clamped and Phi is clamped to
+//             [0, 1], which leaves a tail error of ~1.2e-5 |x| (gelu(-12) = -1.4e-4 where the exact value is ~ -1e-32);
+//   gelu'(x): |error| <= 2.4e-4 at the clamp edge (1.3e-5 for |x| < 3); beyond it the value stays at ~ -2e-4 / 1.0002 where
+//             the exact derivative is 0 / 1.
+// Against the bf16 rounding of what the callers store this is invisible for outputs of magnitude >= 1e-2 (bf16 step >= 4e-5
+// there) and it is NOT for the far negative tail, where the exact output is a tiny number and ours is ~1e-4 in magnitude: an
+// absolute error of 1e-4 on activations that the next GEMM multiplies by weights of ~0.03 and sums with O(1) neighbours.  The
+// parity suite bounds the effect end to end (features / loss / every gradient vs the fp32 oracle).  The epilogues of the fused
+// GEMMs are VALU-bound (profiles/r03_gemm_nta_*.jsonl): ten packed FMAs per pair cost a third of the rcp + exp2 formulation
+// they replace (Abramowitz-Stegun 7.1.26, 2 quarter-rate transcendentals per element).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 clamp2(f32x2 x, float lo, float hi) {
   f32x2 r;

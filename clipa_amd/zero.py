@@ -128,6 +128,10 @@ class ShardedAdamW(torch.optim.Optimizer):
             self._launch(b)
 
     def _launch(self, b):
+        # Invariant: an exchange that a later backward of the same step makes stale is never CONSUMED - its handle is
+        # waited for here (the collective may still be reading b.grad while that backward accumulates into it; the result is
+        # discarded) and step() only reads gshard / recv of the LAST launch (`_finish` relaunches a stale bucket first).  The
+        # plain accum_freq loop therefore moves accum_freq x the bytes; `no_sync()` around all but the last backward avoids it.
         if b.handle is not None:                                  # superseded exchange of an earlier backward: let it drain
             b.handle.wait()
             b.handle = None
@@ -196,6 +200,7 @@ class ShardedAdamW(torch.optim.Optimizer):
                 loss = closure()
         for b in self.buckets:
             self._finish(b)
+            assert not b.stale and b.handle is None, "ShardedAdamW: a stale gradient exchange reached the update"
         # the shards hold the SUM over ranks; DDP's average = sum / W is applied as grad_scale inside the update kernel
         avg = 1.0 / self.world if self._collect else 1.0
         coef = None
