@@ -90,6 +90,25 @@ def plan_keep(budget, layers_v, layers_t, mv_b, mt_b, lv_b, lt_b):
     return int(kv), int(kt), int(mv - kv), int(mt - kt)
 
 
+# What one GB of a kept tensor saves in the backward (ms per GB at ViT-L/16 + text-77, local batch 4096): the e4m3
+# pre-activation replaces the c_fc recompute GEMM by an HBM-bound re-materialisation, the attention output / x1 / qkv each save the
+# kernel that would recompute them (LN1 is needed for the weight gradient either way).  Only the ORDER matters to the planner.
+KEEP_VALUE_MS_PER_GB = (("v", "h8", 1.5), ("t", "h8", 1.13), ("v", "a", 0.94), ("v", "x1", 0.91), ("t", "x1", 0.88),
+                        ("v", "qkv", 0.79), ("t", "a", 0.70), ("t", "qkv", 0.66))
+
+
+def plan_keep_tensors(budget, layers, nbytes):
+    """Greedy per-tensor plan for the bf16 engines: walk KEEP_VALUE_MS_PER_GB, give each (tower, tensor) as many blocks as the
+    budget still holds.  layers: {"v": n, "t": n}; nbytes: {(tower, tensor): bytes per block}.  -> {tower: {tensor: blocks}}."""
+    budget = max(0, int(budget))
+    plan = {tw: {"h8": 0, "a": 0, "x1": 0, "qkv": 0} for tw in layers}
+    for tw, name, _ in KEEP_VALUE_MS_PER_GB:
+        n = min(layers[tw], budget // nbytes[(tw, name)])
+        plan[tw][name] = int(n)
+        budget -= n * nbytes[(tw, name)]
+    return plan
+
+
 def agree_budget(budget, device):
     """Every rank must keep the SAME blocks (identical collectives, identical step time; a rank that keeps more can run
     out of HBM alone): all ranks adopt the smallest activation budget any of them measured."""
@@ -161,6 +180,8 @@ def main():
     ap.add_argument("--keep-blocks", default="auto", help="'auto' or 'LV,LT[,MV,MT]': light-kept (and medium-kept) blocks per tower (image, text)")
     ap.add_argument("--keep-fraction", type=float, default=None,
                     help="share of the free HBM 'auto' may spend (default 0.95 single process, 0.90 with several ranks; a trial step + vote backs the plan off)")
+    ap.add_argument("--tier-plan", action="store_true",
+                    help="plan whole tiers (medium, then light8 upgrades) instead of tensor by tensor (the round-4 default for bf16)")
     ap.add_argument("--no-light8", action="store_true",
                     help="upgrade medium-kept blocks to the bf16 'light' tier instead of 'light8' (e4m3 pre-activations)")
     ap.add_argument("--unpad-text", action="store_true",
@@ -298,8 +319,14 @@ def main():
     # the bf16 engines; the fp8 engine's GEMM has no such epilogue and keeps the bf16 pre-activation ("light", 8 D bytes)
     use_l8 = args.precision != "fp8" and not args.no_light8
 
+    tensor_plan = None                 # bf16 engines under --keep-blocks auto: per-tensor counts (plan_keep_tensors)
+
     def set_keep(kv, kt, mv=0, mt=0):
         vtr, ttr = model.visual.transformer, model.transformer
+        if tensor_plan is not None:
+            vtr.keep_blocks = ttr.keep_blocks = vtr.light8_blocks = ttr.light8_blocks = vtr.medium_blocks = ttr.medium_blocks = 0
+            vtr.keep_counts, ttr.keep_counts = dict(tensor_plan["v"]), dict(tensor_plan["t"])
+            return
         if use_l8:
             vtr.light8_blocks, ttr.light8_blocks, vtr.keep_blocks, ttr.keep_blocks = kv, kt, 0, 0
         else:
@@ -330,7 +357,15 @@ def main():
         lv_b, lt_b = (vt.light8_keep_bytes(B // A * L_img), tt.light8_keep_bytes(B // A * args.ctx)) if use_l8 else \
             (vt.light_keep_bytes(B // A * L_img), tt.light_keep_bytes(B // A * args.ctx))
 
+        per_tensor = use_l8 and not args.tier_plan
+        tok_v, tok_t = B // A * L_img, B // A * args.ctx
+        tb = {(tw, n): tr.tensor_keep_bytes(tok, n) for tw, tr, tok in (("v", vt, tok_v), ("t", tt, tok_t)) for n in ("h8", "a", "x1", "qkv")}
+
         def plan(budget):
+            nonlocal tensor_plan
+            if per_tensor:
+                tensor_plan = plan_keep_tensors(budget, {"v": cfg["vision_cfg"]["layers"], "t": cfg["text_cfg"]["layers"]}, tb)
+                return 0, 0, 0, 0
             return plan_keep(budget, cfg["vision_cfg"]["layers"], cfg["text_cfg"]["layers"], mv_b, mt_b, lv_b, lt_b)
 
         keep_v, keep_t, med_v, med_t = plan(budget0)
@@ -380,6 +415,7 @@ def main():
             keep_v, keep_t, med_v, med_t = plan(budget0)
         else:
             keep_v = keep_t = med_v = med_t = 0        # five plans did not fit: fall back to the all-recompute step that did
+            tensor_plan = None
     else:
         vals = [int(v) for v in args.keep_blocks.split(",")]
         keep_v, keep_t = vals[0], vals[1]
@@ -538,7 +574,7 @@ def main():
             "config": {"workload": f"{args.model}@{args.image_size} + text-{args.ctx}, local batch {B}, "
                                    f"global batch {B * world}, " + (f"accum_freq {A} (feature cache: +1 forward per pair), " if A > 1 else "") +
                                    f"InfoNCE local_loss+gather_with_grad, AdamW, " + ("text tower on the tokens up to EOT (unpad_text), " if args.unpad_text else "") +
-                                   f"block recompute except {int(keep_v)}+{int(keep_t)} {'light8' if use_l8 else 'light'}-kept and {int(med_v)}+{int(med_t)} medium-kept (image+text) blocks", "precision": args.precision, "parallelism": f"dp{world}" + ("" if args.optimizer == "adamw" else f" zero1/{args.exchange}"),
+                                   ("block recompute except kept tensors (image/text blocks) " + ", ".join(f"{n} {tensor_plan['v'][n]}/{tensor_plan['t'][n]}" for n in ("h8", "a", "x1", "qkv")) if tensor_plan is not None else f"block recompute except {int(keep_v)}+{int(keep_t)} {'light8' if use_l8 else 'light'}-kept and {int(med_v)}+{int(med_t)} medium-kept (image+text) blocks"), "precision": args.precision, "parallelism": f"dp{world}" + ("" if args.optimizer == "adamw" else f" zero1/{args.exchange}"),
                        "global_batch": B * world, "train_gflop_per_pair": round(gf, 2)},
             "model_flops_util": round(pairs_s / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4),
             "alloc_conf": args.alloc_conf, "loss": round(last_loss, 4), "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),

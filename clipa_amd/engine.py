@@ -93,23 +93,34 @@ def _block_forward(x, P, cfg, keep, need_y=True):
     B, L, H, causal, act = cfg["B"], cfg["L"], cfg["H"], cfg["causal"], cfg["act"]
     if cfg.get("fp8"):
         return _block_forward_fp8(x, P, cfg, keep, need_y)
+    # the named tiers are sets of kept tensors; a frozenset names them one by one (round 4: what a byte buys differs per tensor -
+    # the e4m3 pre-activation ~1.5 ms per GB, the attention output ~0.94, x1 ~0.91, qkv ~0.79 at ViT-L/16 - so bench.py's planner
+    # keeps them independently): "qkv", "a" (with the softmax statistics), "x1", "h" (bf16 pre-activation) or "h8" (e4m3)
+    ks = KEEP_SETS.get(keep, keep) if keep and keep is not True and keep != "full" else None
+    full = bool(keep) and ks is None
     h1 = ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"])
     qkv = ops.gemm_nt(h1, P["w_in"], P["b_in"])
-    a, stats = _attn_fwd(qkv, cfg, bool(keep))
+    a, stats = _attn_fwd(qkv, cfg, full or (ks is not None and "a" in ks))
     x1 = ops.gemm_nt(a, P["w_out"], P["b_out"], epi=ops.EPI_ADD, aux=x)
     h2 = ops.layernorm_fwd(x1, P["ln2_w"], P["ln2_b"], cfg["eps"])
-    if keep and keep != "medium":
-        g, hpre = ops.gemm_nt(h2, P["w_fc"], P["b_fc"], epi=ops.EPI_ACT, act=act, want_pre="e4m3" if keep == "light8" else True)
+    want_pre = "e4m3" if (ks is not None and "h8" in ks) else (full or (ks is not None and "h" in ks))
+    if want_pre:
+        g, hpre = ops.gemm_nt(h2, P["w_fc"], P["b_fc"], epi=ops.EPI_ACT, act=act, want_pre=want_pre)
     else:
         g, hpre = ops.gemm_nt(h2, P["w_fc"], P["b_fc"], epi=ops.EPI_ACT, act=act), None
     # (need_y=False: the backward-time recompute of a block wants the intermediates only - its output is the next block's input,
     # which that block kept; the c_proj GEMM would be thrown away)
     y = ops.gemm_nt(g, P["w_proj"], P["b_proj"], epi=ops.EPI_ADD, aux=x1) if need_y else None
-    if keep in ("light", "light8", "medium"):
-        return y, (None, qkv, a, stats, x1, None, hpre, None)
-    if keep:
+    if full:
         return y, (h1, qkv, a, stats, x1, h2, hpre, g)
+    if ks:
+        return y, (None, qkv if "qkv" in ks else None, a if "a" in ks else None, stats if "a" in ks else None,
+                   x1 if "x1" in ks else None, None, hpre, None)
     return y, None
+
+
+KEEP_SETS = {"light": frozenset(("qkv", "a", "x1", "h")), "light8": frozenset(("qkv", "a", "x1", "h8")),
+             "medium": frozenset(("qkv", "a", "x1"))}
 
 
 def _lin8(xq, xs, P, name, **kw):
@@ -134,6 +145,8 @@ def _block_forward_fp8(x, P, cfg, keep, need_y=True):
     B, L, H, causal, act = cfg["B"], cfg["L"], cfg["H"], cfg["causal"], cfg["act"]
     if keep == "light8":          # the e4m3 pre-activation copy is an epilogue of the bf16 GEMM only: plain light keep here
         keep = "light"
+    if isinstance(keep, frozenset):   # per-tensor keep sets are a bf16-engine feature: the nearest named tier here
+        keep = "light" if ("h" in keep or "h8" in keep) else ("medium" if keep else False)
     full = bool(keep) and keep not in ("light", "medium")
     h1, q1, s1 = ops.layernorm_fwd_q8(x, P["ln1_w"], P["ln1_b"], cfg["eps"], want_bf16=full)
     qkv = _lin8(q1, s1, P, "in")
@@ -166,6 +179,15 @@ def _block_backward(x, dy, box, P, cfg):
     h1, qkv, a, stats, x1, h2, hpre, g = box.pop()
     dy = dy.contiguous()
     fp8 = bool(cfg.get("fp8"))
+    if not fp8:
+        # tensors the block did not keep are recomputed here, bit for bit as the forward produced them
+        if qkv is None:
+            h1 = ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"])
+            qkv = ops.gemm_nt(h1, P["w_in"], P["b_in"])
+        if a is None:
+            a, stats = _attn_fwd(qkv, cfg, True)
+        if x1 is None:
+            x1 = ops.gemm_nt(a, P["w_out"], P["b_out"], epi=ops.EPI_ADD, aux=x)
     if hpre is None and fp8:
         h2, q2, s2 = ops.layernorm_fwd_q8(x1, P["ln2_w"], P["ln2_b"], cfg["eps"], want_bf16=True)
         g, hpre = _lin8(q2, s2, P, "fc", epi=ops.EPI_ACT, act=act, want_pre=True)

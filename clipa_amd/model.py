@@ -154,6 +154,9 @@ class Transformer(nn.Module):
         # per token): no GEMM is re-run, gelu'(h) and the re-materialised activation come from the rounded value
         # (engine._block_forward).  Order of the tiers along the depth: light, light8, medium, recompute.
         self.light8_blocks = 0
+        # ... or tensor by tensor (bf16 engines; what bench.py's planner uses): the first keep_counts[t] blocks keep tensor t
+        # ("h8" e4m3 pre-activation, "a" attention output + statistics, "x1", "qkv"), on top of the named tiers above
+        self.keep_counts = {"h8": 0, "a": 0, "x1": 0, "qkv": 0}
         # fp8 engine mode (create_model(precision="fp8"), BASELINE.json configs[3]): the four linear layers of every block run
         # forward and input-gradient GEMMs on e4m3 operands (engine._block_forward_fp8); "e5m2" switches the gradient operand
         self.fp8 = False
@@ -175,8 +178,13 @@ class Transformer(nn.Module):
         light8 = dict(base, keep_this=True, keep="light8")
         n1, n2 = self.keep_blocks, self.keep_blocks + self.light8_blocks
         last = len(self.resblocks) - 1
+        counted = any(self.keep_counts.values()) and not self.fp8
         for i, blk in enumerate(self.resblocks):
             cfg = kept if i < n1 else (light8 if i < n2 else (medium if i < n2 + self.medium_blocks else base))
+            if counted:
+                ks = frozenset(t for t, n in self.keep_counts.items() if i < n) | engine.KEEP_SETS.get(cfg["keep"] if cfg is not base else None, frozenset())
+                if ks:
+                    cfg = dict(base, keep_this=True, keep=ks)
             if i == last and pooled_rows is not None and not self.fp8:
                 return engine.LastBlockFn.apply(x, pooled_rows, cfg, cache, *blk.param_tuple())
             x = engine.ResBlockFn.apply(x, cfg, cache, *blk.param_tuple())
@@ -188,6 +196,12 @@ class Transformer(nn.Module):
 
     def light8_keep_bytes(self, tokens):
         return tokens * 7 * self.width * 2 + tokens * self.heads * 8   # qkv, a, x1 (bf16), hpre (e4m3: 4 * width bytes) + stats
+
+    def tensor_keep_bytes(self, tokens, name):
+        """HBM bytes of one kept tensor of one block (keep_counts)."""
+        mlp = self.resblocks[0].mlp.c_fc.weight.shape[0]
+        return {"qkv": tokens * 3 * self.width * 2, "a": tokens * self.width * 2 + tokens * self.heads * 8,
+                "x1": tokens * self.width * 2, "h8": tokens * mlp, "h": tokens * mlp * 2}[name]
 
     def medium_keep_bytes(self, tokens):
         return tokens * 5 * self.width * 2 + tokens * self.heads * 8   # qkv, a, x1 (bf16) + softmax stats

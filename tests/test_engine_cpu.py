@@ -173,6 +173,50 @@ def test_light8_tier_keeps_the_forward_and_stays_close_in_backward(golden):
     print(f"[{g.name}] light8 vs recompute: worst gradient cosine {worst:.6f}")
 
 
+def _run_counts(g, counts):
+    m = clipa_amd.CLIP(**g.cfg, output_dict=True)
+    m.load_state_dict(g.sd, strict=True)
+    m.set_grad_checkpointing(True)
+    for t in (m.visual.transformer, m.transformer):
+        t.keep_counts = dict(t.keep_counts, **counts)
+    out = m(g.images_u8, g.texts)
+    loss = clipa_amd.ClipLoss()(**out, output_dict=True)["contrastive_loss"]
+    loss.backward()
+    return m, loss
+
+
+@pytest.mark.parametrize("counts", [{"a": 2}, {"x1": 1}, {"qkv": 2, "x1": 1}, {"a": 1, "qkv": 2}, {"qkv": 1, "a": 2, "x1": 2}])
+def test_per_tensor_keep_sets_equal_recompute(counts):
+    """bench.py's planner keeps a block's tensors one by one (keep_counts): whatever subset of qkv / attention output / x1 is
+    kept, the rest is recomputed bit for bit - same loss, same gradients as the all-recompute step."""
+    g = load_golden("cls_erf")
+    ma, _, la = _run(g, recompute=True)
+    mb, lb = _run_counts(g, counts)
+    assert float(la) == float(lb)
+    for (k, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
+        if p.grad is not None:
+            assert torch.equal(p.grad, q.grad), (counts, k)
+
+
+def test_per_tensor_keep_with_e4m3_pre_activation():
+    """h8 without its neighbours: the e4m3 pre-activation kept while qkv / attention output / x1 are recomputed (the most
+    valuable bytes first).  Same gradients as the light8 tier on every block (the recomputed tensors are exact)."""
+    g = load_golden("cls_erf")
+    ma, la = _run_counts(g, {"h8": 2})
+    mb = clipa_amd.CLIP(**g.cfg, output_dict=True)
+    mb.load_state_dict(g.sd, strict=True)
+    mb.set_grad_checkpointing(True)
+    for t in (mb.visual.transformer, mb.transformer):
+        t.light8_blocks = t.layers
+    out = mb(g.images_u8, g.texts)
+    lb = clipa_amd.ClipLoss()(**out, output_dict=True)["contrastive_loss"]
+    lb.backward()
+    assert float(la) == float(lb)
+    for (k, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
+        if p.grad is not None:
+            assert torch.equal(p.grad, q.grad), k
+
+
 def test_bf16_precision_mode_and_frozen_tower(golden):
     m, _, loss = _run(golden, precision="bf16")
     for k, p in m.named_parameters():

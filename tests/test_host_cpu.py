@@ -196,6 +196,29 @@ def test_bench_keep_planner_respects_the_budget():
     assert bench.plan_keep(2000 << 30, 24, 12, mv, mt, lv, lt) == (24, 12, 0, 0)
 
 
+def test_bench_per_tensor_planner():
+    """The bf16 engines' planner keeps tensors one by one, most valuable bytes first (e4m3 pre-activation, attention output,
+    x1, qkv; image tower before text at equal kind): never over budget, monotone in the budget, and at the headline shape's
+    budget every image block keeps its e4m3 pre-activation before any block keeps qkv."""
+    import bench
+    m = clipa_amd.create_model("ViT-L-16")
+    tok = {"v": 4096 * 197, "t": 4096 * 77}
+    tr = {"v": m.visual.transformer, "t": m.transformer}
+    nb = {(tw, n): tr[tw].tensor_keep_bytes(tok[tw], n) for tw in tr for n in ("h8", "a", "x1", "qkv")}
+    assert nb[("v", "h8")] == tok["v"] * 4096 and nb[("v", "qkv")] == tok["v"] * 3 * 1024 * 2
+    prev = -1
+    for gb in (0, 3, 50, 100, 200, 400, 2000):
+        plan = bench.plan_keep_tensors(gb << 30, {"v": 24, "t": 12}, nb)
+        used = sum(plan[tw][n] * nb[(tw, n)] for tw in plan for n in plan[tw])
+        assert used <= (gb << 30)
+        kept = sum(plan[tw][n] for tw in plan for n in plan[tw])
+        assert kept >= prev
+        prev = kept
+    plan = bench.plan_keep_tensors(200 << 30, {"v": 24, "t": 12}, nb)
+    assert plan["v"]["h8"] == 24 and plan["v"]["a"] == 24 and plan["v"]["x1"] == 24 and plan["v"]["qkv"] < 24
+    assert bench.plan_keep_tensors(2000 << 30, {"v": 24, "t": 12}, nb) == {tw: {"h8": n, "a": n, "x1": n, "qkv": n} for tw, n in (("v", 24), ("t", 12))}
+
+
 def test_optimizer_load_state_dict_restores_f32_moments():
     """torch.optim.Optimizer.load_state_dict casts floating-point state to the parameter's dtype; the HIP kernel reads
     the moments as float*, so clipa_amd.optim.AdamW must restore f32 (and an int step) after a resume - also from a

@@ -374,6 +374,27 @@ def test_unpadded_text_tower_changes_nothing(case):
         assert torch.allclose(p.grad.float(), q.grad.float(), rtol=3e-2, atol=1e-5 * float(p.grad.float().abs().max()) + 1e-9), k
 
 
+@pytest.mark.parametrize("counts", [{"a": 2}, {"qkv": 2, "x1": 1}, {"h8": 2, "a": 1}])
+def test_per_tensor_keep_sets(counts):
+    """bench.py's planner keeps a block's tensors one by one (Transformer.keep_counts): whatever subset of qkv / attention
+    output / x1 is kept, the rest is recomputed bit for bit (same loss and gradients as the all-recompute step); with the e4m3
+    pre-activation among them the gradients are those of the light8 tier."""
+    g = load_golden("cls_erf")
+    ref = _engine(g)
+    if "h8" in counts:
+        for t in (ref.visual.transformer, ref.transformer):
+            t.light8_blocks = t.layers
+    _, l0 = _step(ref, g)
+    m = _engine(g)
+    for t in (m.visual.transformer, m.transformer):
+        t.keep_counts = dict(t.keep_counts, **counts)
+    _, l1 = _step(m, g)
+    assert float(l0) == float(l1)
+    for (k, p), (_, q) in zip(ref.named_parameters(), m.named_parameters()):
+        if p.grad is not None:
+            assert torch.equal(p.grad, q.grad), (counts, k)
+
+
 def test_input_formats_agree():
     """uint8 NCHW, uint8 channels_last and pre-normalised float inputs give the same features."""
     g = load_golden("cls_erf")
