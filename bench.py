@@ -179,7 +179,7 @@ def main():
                          "configs[3]: bf16 weights / activations, e4m3 operands for the block GEMMs (forward + input gradient)")
     ap.add_argument("--keep-blocks", default="auto", help="'auto' or 'LV,LT[,MV,MT]': light-kept (and medium-kept) blocks per tower (image, text)")
     ap.add_argument("--keep-fraction", type=float, default=None,
-                    help="share of the free HBM 'auto' may spend (default 0.97 single process, 0.90 with several ranks; a trial step + vote backs the plan off)")
+                    help="share of the free HBM 'auto' may spend (default 0.97 single process, 0.94 with several ranks; a trial step + vote backs the plan off)")
     ap.add_argument("--tier-plan", action="store_true",
                     help="plan whole tiers (medium, then light8 upgrades) instead of tensor by tensor (the round-4 default for bf16)")
     ap.add_argument("--no-light8", action="store_true",
@@ -346,7 +346,7 @@ def main():
         peak = torch.cuda.max_memory_allocated(dev)
         # several ranks: a little less than alone (RCCL's channel buffers and the gathered features grow with the world size;
         # the trial below is collective-free), and the vote after the trial backs every rank off together if it was too much
-        frac = args.keep_fraction if args.keep_fraction is not None else (0.90 if dist_on else 0.97)
+        frac = args.keep_fraction if args.keep_fraction is not None else (0.94 if dist_on else 0.97)
         budget0 = int(frac * (total_mem - peak)) - (6 << 30)
         if dist_on:
             budget0 = agree_budget(budget0, dev)
