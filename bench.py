@@ -327,6 +327,7 @@ def main():
             vtr.keep_blocks = ttr.keep_blocks = vtr.light8_blocks = ttr.light8_blocks = vtr.medium_blocks = ttr.medium_blocks = 0
             vtr.keep_counts, ttr.keep_counts = dict(tensor_plan["v"]), dict(tensor_plan["t"])
             return
+        vtr.keep_counts, ttr.keep_counts = ({"h8": 0, "a": 0, "x1": 0, "qkv": 0} for _ in range(2))
         if use_l8:
             vtr.light8_blocks, ttr.light8_blocks, vtr.keep_blocks, ttr.keep_blocks = kv, kt, 0, 0
         else:
@@ -350,9 +351,8 @@ def main():
         budget0 = int(frac * (total_mem - peak)) - (6 << 30)
         if dist_on:
             budget0 = agree_budget(budget0, dev)
-        # Spend the budget where a byte saves the most recompute FLOPs: "medium" tier first (drops LN1, in-proj,
-        # attention, out-proj: ~17.5 of a block's 25.5 D^2 units for 5 D bytes per token), image tower before
-        # text (wider), then upgrades medium -> "light" (the remaining 8 units for 4 more D bytes).
+        # Spend the budget where a byte saves the most step time: tensor by tensor for the bf16 engines (plan_keep_tensors), whole
+        # tiers for fp8 / --tier-plan (plan_keep: medium first, then its upgrades).
         mv_b, mt_b = vt.medium_keep_bytes(B // A * L_img), tt.medium_keep_bytes(B // A * args.ctx)     # per micro-batch
         lv_b, lt_b = (vt.light8_keep_bytes(B // A * L_img), tt.light8_keep_bytes(B // A * args.ctx)) if use_l8 else \
             (vt.light_keep_bytes(B // A * L_img), tt.light_keep_bytes(B // A * args.ctx))
