@@ -65,7 +65,7 @@ def test_isa_audit(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     a = subprocess.run([sys.executable, os.path.join(ROOT, "clipa_amd", "isa_audit.py"), str(asm)], capture_output=True, text=True)
     assert a.returncode == 0, a.stdout[-3000:]
-    assert len(re.findall(r"\.name:\s+\S*gemm_nta_kernel", asm.read_text())) == 15
+    assert len(re.findall(r"\.name:\s+\S*gemm_nta_kernel", asm.read_text())) == 21      # 7 epilogue flavours (5 + the two e4m3 ones) x 3 schedules
 
 
 @pytest.mark.parametrize("sched", [0, 1])
@@ -168,10 +168,15 @@ def test_audit_counts_the_epilogue_stores(tmp_path):
     epilogue with fewer (merged / dropped) stores would let operands be read before they landed.  Every copy is
     bracketed by markers and counted; a missing marker pair is a finding as well."""
     from clipa_amd import isa_audit
-    head = "_ZN10clipa_gemm12_GLOBAL__N_115gemm_nta_kernelILi1ELb1ELi4EEEvNS_6NTArgsE:\n"
+    head = "_ZN10clipa_gemm12_GLOBAL__N_115gemm_nta_kernelILi1ELi1ELb0ELi4EEEvNS_6NTArgsE:\n"       # <ACT, PRE = 1 (bf16 copy), ., .>
     st = "\tbuffer_store_dwordx4 v[6:9], v101, s[40:43], s96 offen\n\ts_nop 0\n"
-    def body(n):
-        return head + "\t;;#ASMSTART\n\t; CLIPA_EPI_BEGIN 0\n\t;;#ASMEND\n" + st * n + "\t;;#ASMSTART\n\t; CLIPA_EPI_END 0\n\t;;#ASMEND\n.Lfunc_end0:\n"
+    st8 = "\tbuffer_store_dwordx2 v[6:7], v101, s[40:43], s96 offen\n\ts_nop 0\n"
+    def body(n, n8=0, h=head):
+        return h + "\t;;#ASMSTART\n\t; CLIPA_EPI_BEGIN 0\n\t;;#ASMEND\n" + st * n + st8 * n8 + "\t;;#ASMSTART\n\t; CLIPA_EPI_END 0\n\t;;#ASMEND\n.Lfunc_end0:\n"
+    head8 = head.replace("ILi1ELi1E", "ILi1ELi2E")                                                    # PRE = 2: e4m3 copy = 8-byte stores
+    assert isa_audit.epilogue_store_counts("x", body(32, 32, head8).splitlines()) == []
+    assert len(isa_audit.epilogue_store_counts("x", body(32, 31, head8).splitlines())) == 1
+    assert len(isa_audit.epilogue_store_counts("x", body(64, 0, head8).splitlines())) == 1
     assert isa_audit.epilogue_store_counts("x", body(64).splitlines()) == []          # PRE: two outputs x 32
     assert len(isa_audit.epilogue_store_counts("x", body(63).splitlines())) == 1
     assert len(isa_audit.epilogue_store_counts("x", body(65).splitlines())) == 1
