@@ -2,29 +2,37 @@
 // Replaces F.layer_norm in clipa_torch/open_clip/transformer.py:19-34 (LayerNorm / LayerNormFp32:
 // biased variance, eps inside the sqrt, affine) and its autograd.
 // HBM-bound: every row is read once with 16-byte loads and kept in registers for both passes.
+// Grid shapes and cache policy follow tools/probes/stream_ab.hip (profiles/r04_stream_kernel_shapes_ab_*.jsonl, rows = 806912,
+// D = 1024): a ONE-SHOT grid (a block lives for 8 rows) streams at 6.1 TB/s where 2048 persistent blocks striding the rows
+// reach 4.7, and non-temporal loads + stores of the row streams are worth another 4 %; the backward kernel, which has to carry
+// dgamma / dbeta partials, gives every block 128 ADJACENT rows (5.4 TB/s including the partial reduction, 4.4 persistent).
 #include "common.h"
 #include "clipa_hip.h"
 
 namespace {
 
 // load / store 8 consecutive elements as float
-template <bool F32>
+// STREAM: the operand is a row stream that this kernel touches once (non-temporal); gamma / beta are not
+template <bool F32, bool STREAM = true>
 __device__ __forceinline__ void ld8(const void* base, size_t elem, float* f) {
   if (F32) {
-    const float4 a = *(const float4*)((const float*)base + elem);
-    const float4 b = *(const float4*)((const float*)base + elem + 4);
+    const f32x4* p = (const f32x4*)((const float*)base + elem);
+    const f32x4 a = STREAM ? __builtin_nontemporal_load(p) : p[0];
+    const f32x4 b = STREAM ? __builtin_nontemporal_load(p + 1) : p[1];
     f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
   } else {
-    unpack8(*(const u32x4*)((const unsigned short*)base + elem), f);
+    const u32x4* p = (const u32x4*)((const unsigned short*)base + elem);
+    unpack8(STREAM ? __builtin_nontemporal_load(p) : *p, f);
   }
 }
 template <bool F32>
 __device__ __forceinline__ void st8(void* base, size_t elem, const float* f) {
   if (F32) {
-    *(float4*)((float*)base + elem) = make_float4(f[0], f[1], f[2], f[3]);
-    *(float4*)((float*)base + elem + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    f32x4* p = (f32x4*)((float*)base + elem);
+    __builtin_nontemporal_store(f32x4{f[0], f[1], f[2], f[3]}, p);
+    __builtin_nontemporal_store(f32x4{f[4], f[5], f[6], f[7]}, p + 1);
   } else {
-    *(u32x4*)((unsigned short*)base + elem) = pack8(f);
+    __builtin_nontemporal_store(pack8(f), (u32x4*)((unsigned short*)base + elem));
   }
 }
 
@@ -41,12 +49,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int ch = lane + c * 64;
-    if (ch < nchunks) { ld8<true>(gamma, (size_t)ch * 8, g[c]); ld8<true>(beta, (size_t)ch * 8, bt[c]); }
+    if (ch < nchunks) { ld8<true, false>(gamma, (size_t)ch * 8, g[c]); ld8<true, false>(beta, (size_t)ch * 8, bt[c]); }
   }
   const float invD = 1.0f / (float)D;
-  // TWO rows per wave and iteration: both rows' loads are in flight before the first reduction starts (one row of 2 KB per
-  // wave does not cover the HBM latency at 32 waves per CU: 4.3 TB/s; the backward kernel, which has three loads per row in
-  // flight, runs at the roof)
+  // TWO rows per wave and iteration, both rows' loads in flight before the first reduction starts; the launcher sizes the
+  // grid so that this loop runs ONCE (the loop remains for row counts beyond the grid limit)
   for (long r = wid; r < rows; r += 2 * nw) {
     const long r2 = r + nw;
     const bool two = r2 < rows;
@@ -104,12 +111,12 @@ template <int NCH, bool XF32, bool YF32>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
                                                      const void* __restrict__ dy, const void* __restrict__ dres,
                                                      void* __restrict__ dx, float* __restrict__ part,
-                                                     long rows, int D, float eps) {
+                                                     long rows, int D, float eps, int C) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
-  const long wid = (long)blockIdx.x * 4 + wv;
-  const long nw = (long)gridDim.x * 4;
+  // block b owns the C adjacent rows [b C, (b + 1) C); its four waves take them interleaved (one 4-row window per step)
+  const long row_end = rows < (long)(blockIdx.x + 1) * C ? rows : (long)(blockIdx.x + 1) * C;
   const int nchunks = D >> 3;
   float g[NCH][8], dg[NCH][8], db[NCH][8];
 #pragma unroll
@@ -117,10 +124,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
     const int ch = lane + c * 64;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { dg[c][i] = 0.f; db[c][i] = 0.f; g[c][i] = 0.f; }
-    if (ch < nchunks) ld8<true>(gamma, (size_t)ch * 8, g[c]);
+    if (ch < nchunks) ld8<true, false>(gamma, (size_t)ch * 8, g[c]);
   }
   const float invD = 1.0f / (float)D;
-  for (long r = wid; r < rows; r += nw) {
+  for (long r = (long)blockIdx.x * C + wv; r < row_end; r += 4) {
     float v[NCH][8], d[NCH][8];
     float s = 0.f;
 #pragma unroll
@@ -204,23 +211,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
   }
 }
 
-// out[which][col] = sum_b part[which][b][col]
-// 64 columns per block, 4 waves striding the partial rows (4 independent loads in flight per lane)
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int nblk, int D) {
+// out_g[y][col] = sum over the partial rows b of slice y of part[0][b][col], out_b likewise from part[1]:
+// 64 columns per block, 4 waves striding the slice (4 independent loads in flight per lane).  Many partial rows are reduced in
+// two passes (gridDim.y slices -> [2][slices][D], then one slice over those) so that the first pass fills the chip.
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ out_g,
+                                                            float* __restrict__ out_b, int nblk, int D, int per) {
   __shared__ float red[2][4][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + lane;
+  const int lo = blockIdx.y * per, hi = lo + per < nblk ? lo + per : nblk;
   float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
   if (col < D) {
-    int s = grp;
-    for (; s + 4 < nblk; s += 8) {
+    int s = lo + grp;
+    for (; s + 4 < hi; s += 8) {
       a0 += part[(size_t)s * D + col];
       a1 += part[(size_t)(s + 4) * D + col];
       b0 += part[((size_t)nblk + s) * D + col];
       b1 += part[((size_t)nblk + s + 4) * D + col];
     }
-    for (; s < nblk; s += 4) {
+    for (; s < hi; s += 4) {
       a0 += part[(size_t)s * D + col];
       b0 += part[((size_t)nblk + s) * D + col];
     }
@@ -229,22 +238,30 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
   red[1][grp][lane] = b0 + b1;
   __syncthreads();
   if (grp == 0 && col < D) {
-    dgamma[col] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
-    dbeta[col] = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+    out_g[(size_t)blockIdx.y * D + col] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+    out_b[(size_t)blockIdx.y * D + col] = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
   }
 }
 
-int ln_grid(long rows, long cap = 2048) {
-  long g = (rows + 3) / 4;
-  if (g > cap) g = cap;
+// forward: one block per 8 rows (4 waves x 2 rows), i.e. the row loop of ln_fwd_kernel runs once
+int ln_fwd_grid(long rows) {
+  long g = (rows + 7) / 8;
+  if (g > 0x7fffffffL) g = 0x7fffffffL;
   if (g < 1) g = 1;
   return (int)g;
 }
+// backward: rows per block - 128 where that still leaves >= 2048 blocks, fewer (a multiple of 4) for short inputs
+constexpr int LN_BWD_SLICES = 16;
+int ln_bwd_chunk(long rows) {
+  long c = (rows / 2048 + 3) / 4 * 4;
+  return (int)(c < 4 ? 4 : (c > 128 ? 128 : c));
+}
+long ln_bwd_grid(long rows) { const long c = ln_bwd_chunk(rows); return (rows + c - 1) / c; }
 
 template <int NCH>
 void launch_fwd(const void* x, const float* g, const float* b, void* y, long rows, int D, float eps,
                 int xf32, int yf32, hipStream_t st) {
-  const int grid = ln_grid(rows);
+  const int grid = ln_fwd_grid(rows);
   if (xf32 && yf32) hipLaunchKernelGGL((ln_fwd_kernel<NCH, true, true>), dim3(grid), dim3(256), 0, st, x, g, b, y, rows, D, eps);
   else if (xf32) hipLaunchKernelGGL((ln_fwd_kernel<NCH, true, false>), dim3(grid), dim3(256), 0, st, x, g, b, y, rows, D, eps);
   else if (yf32) hipLaunchKernelGGL((ln_fwd_kernel<NCH, false, true>), dim3(grid), dim3(256), 0, st, x, g, b, y, rows, D, eps);
@@ -252,12 +269,12 @@ void launch_fwd(const void* x, const float* g, const float* b, void* y, long row
 }
 template <int NCH>
 void launch_bwd(const void* x, const float* g, const void* dy, const void* dres, void* dx, float* part,
-                long rows, int D, float eps, int xf32, int yf32, int grid, hipStream_t st) {
+                long rows, int D, float eps, int xf32, int yf32, int grid, int C, hipStream_t st) {
   const size_t lds = (size_t)8 * D * sizeof(float);
-  if (xf32 && yf32) hipLaunchKernelGGL((ln_bwd_kernel<NCH, true, true>), dim3(grid), dim3(256), lds, st, x, g, dy, dres, dx, part, rows, D, eps);
-  else if (xf32) hipLaunchKernelGGL((ln_bwd_kernel<NCH, true, false>), dim3(grid), dim3(256), lds, st, x, g, dy, dres, dx, part, rows, D, eps);
-  else if (yf32) hipLaunchKernelGGL((ln_bwd_kernel<NCH, false, true>), dim3(grid), dim3(256), lds, st, x, g, dy, dres, dx, part, rows, D, eps);
-  else hipLaunchKernelGGL((ln_bwd_kernel<NCH, false, false>), dim3(grid), dim3(256), lds, st, x, g, dy, dres, dx, part, rows, D, eps);
+  if (xf32 && yf32) hipLaunchKernelGGL((ln_bwd_kernel<NCH, true, true>), dim3(grid), dim3(256), lds, st, x, g, dy, dres, dx, part, rows, D, eps, C);
+  else if (xf32) hipLaunchKernelGGL((ln_bwd_kernel<NCH, true, false>), dim3(grid), dim3(256), lds, st, x, g, dy, dres, dx, part, rows, D, eps, C);
+  else if (yf32) hipLaunchKernelGGL((ln_bwd_kernel<NCH, false, true>), dim3(grid), dim3(256), lds, st, x, g, dy, dres, dx, part, rows, D, eps, C);
+  else hipLaunchKernelGGL((ln_bwd_kernel<NCH, false, false>), dim3(grid), dim3(256), lds, st, x, g, dy, dres, dx, part, rows, D, eps, C);
 }
 
 }  // namespace
@@ -275,7 +292,7 @@ extern "C" int clipa_layernorm_fwd(const void* x, const float* gamma, const floa
 }
 
 extern "C" int64_t clipa_layernorm_bwd_workspace(int64_t rows, int64_t D) {
-  return (int64_t)2 * ln_grid(rows, 1024) * D * sizeof(float);
+  return (int64_t)2 * (ln_bwd_grid(rows) + LN_BWD_SLICES) * D * sizeof(float);   // [2][blocks][D] + [2][slices][D]
 }
 
 extern "C" int clipa_layernorm_bwd(const void* x, const float* gamma, const void* dy, const void* dres,
@@ -286,13 +303,22 @@ extern "C" int clipa_layernorm_bwd(const void* x, const float* gamma, const void
   if (rows <= 0) return CLIPA_OK;
   if (!workspace || workspace_bytes < clipa_layernorm_bwd_workspace(rows, D)) { clipa_set_error("layernorm_bwd: workspace too small"); return CLIPA_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
-  const int grid = ln_grid(rows, 1024);
+  const int grid = (int)ln_bwd_grid(rows), C = ln_bwd_chunk(rows);
   float* part = (float*)workspace;
-  if (D <= 512) launch_bwd<1>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, st);
-  else if (D <= 1024) launch_bwd<2>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, st);
-  else if (D <= 1536) launch_bwd<3>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, st);
-  else launch_bwd<4>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, st);
+  if (D <= 512) launch_bwd<1>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, C, st);
+  else if (D <= 1024) launch_bwd<2>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, C, st);
+  else if (D <= 1536) launch_bwd<3>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, C, st);
+  else launch_bwd<4>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, C, st);
   if (int rc = clipa_check_launch("layernorm_bwd")) return rc;
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((D + 63) / 64)), dim3(256), 0, st, part, dgamma, dbeta, grid, (int)D);
-  return clipa_check_launch("layernorm_bwd_reduce");
+  const unsigned cols = (unsigned)((D + 63) / 64);
+  if (grid <= 8 * LN_BWD_SLICES) {
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cols), dim3(256), 0, st, part, dgamma, dbeta, grid, (int)D, grid);
+    return clipa_check_launch("layernorm_bwd_reduce");
+  }
+  float* part2 = part + (size_t)2 * grid * D;
+  const int per = (grid + LN_BWD_SLICES - 1) / LN_BWD_SLICES;
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cols, LN_BWD_SLICES), dim3(256), 0, st, part, part2, part2 + (size_t)LN_BWD_SLICES * D, grid, (int)D, per);
+  if (int rc = clipa_check_launch("layernorm_bwd_reduce")) return rc;
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cols), dim3(256), 0, st, part2, dgamma, dbeta, LN_BWD_SLICES, (int)D, LN_BWD_SLICES);
+  return clipa_check_launch("layernorm_bwd_reduce2");
 }

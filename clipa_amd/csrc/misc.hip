@@ -421,7 +421,9 @@ __global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict_
   }
 }
 
-inline unsigned grid_for(long work, int block = 256, long cap = 8192) {
+// one-shot by default: a thread per work item (a persistent grid striding a large array streams a third slower than one block
+// per 4 KB - tools/probes/stream_ab.hip, copy 4.6 vs 6.2 TB/s); the kernels keep their grid-stride loops for the > 2^31 case
+inline unsigned grid_for(long work, int block = 256, long cap = 0x7fffffffL) {
   long g = (work + block - 1) / block;
   if (g > cap) g = cap;
   if (g < 1) g = 1;
@@ -672,14 +674,14 @@ template <int ACT>
 __global__ void activation_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out, long n8) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
     float f[8];
-    unpack8(*(const u32x4*)(in + i * 8), f);
+    unpack8(ld_stream<u32x4>(in + i * 8), f);
 #pragma unroll
     for (int k = 0; k < 8; k += 2) {
       const f32x2 r = act_fwd2<ACT>(f32x2{f[k], f[k + 1]});
       f[k] = r.x;
       f[k + 1] = r.y;
     }
-    *(u32x4*)(out + i * 8) = pack8(f);
+    st_stream<u32x4>(out + i * 8, pack8(f));
   }
 }
 }  // namespace

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const char* __restri
     const int ch = lane + c * 64;
     v[c] = u32x4{0, 0, 0, 0};
     if (ch < nchunks) {
-      v[c] = *(const u32x4*)(x + ((size_t)row * ldx + (size_t)ch * 8) * 2);
+      v[c] = ld_stream<u32x4>(x + ((size_t)row * ldx + (size_t)ch * 8) * 2);
       float f[8];
       unpack8(v[c], f);
 #pragma unroll
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const char* __restri
     if (ch < nchunks) {
       float f[8];
       unpack8(v[c], f);
-      *(u32x2*)(q + (size_t)row * ldq + (size_t)ch * 8) = cvt8<FMT>(f, s);
+      st_stream<u32x2>(q + (size_t)row * ldq + (size_t)ch * 8, cvt8<FMT>(f, s));
     }
   }
 }
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void ln_fwd_q8_kernel(const char* __restrict__
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[c][i] = 0.f;
       if (ch < nchunks) {
-        unpack8(*(const u32x4*)(x + ((size_t)r * D + (size_t)ch * 8) * 2), v[c]);
+        unpack8(ld_stream<u32x4>(x + ((size_t)r * D + (size_t)ch * 8) * 2), v[c]);
 #pragma unroll
         for (int i = 0; i < 8; ++i) sum += v[c][i];
       }
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void ln_fwd_q8_kernel(const char* __restrict__
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = (v[c][i] - mean) * rstd * g[c][i] + bt[c][i];
         yb[c] = pack8(o);                       // the bf16 rounding of the plain LayerNorm kernel: q is derived from it
-        if (y) *(u32x4*)(y + ((size_t)r * D + (size_t)ch * 8) * 2) = yb[c];
+        if (y) st_stream<u32x4>(y + ((size_t)r * D + (size_t)ch * 8) * 2, yb[c]);
         unpack8(yb[c], o);
 #pragma unroll
         for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(o[i]));
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void ln_fwd_q8_kernel(const char* __restrict__
       if (ch < nchunks) {
         float o[8];
         unpack8(yb[c], o);
-        *(u32x2*)(q + (size_t)r * D + (size_t)ch * 8) = cvt8<0>(o, s);
+        st_stream<u32x2>(q + (size_t)r * D + (size_t)ch * 8, cvt8<0>(o, s));
       }
     }
   }
@@ -187,8 +187,8 @@ extern "C" int clipa_layernorm_fwd_q8(const void* x, const float* gamma, const f
                                       int64_t rows, int64_t D, float eps, void* stream) {
   if (rows <= 0) return CLIPA_OK;
   if (D <= 0 || D % 8 != 0 || D > 2048) { clipa_set_error("layernorm_fwd_q8: D=%ld must be a multiple of 8 in (0, 2048]", (long)D); return CLIPA_ERR_ARG; }
-  long blocks = (rows + 3) / 4;
-  if (blocks > 2048) blocks = 2048;                // grid-stride over rows (as layernorm.hip): gamma / beta stay in registers
+  long blocks = (rows + 3) / 4;                    // one-shot grid, a wave per row (as layernorm.hip; the row loop is for > 2^33 rows)
+  if (blocks > 0x7fffffffL) blocks = 0x7fffffffL;
   const dim3 grid((unsigned)blocks), block(256);
   hipStream_t st = (hipStream_t)stream;
   const char* xp = (const char*)x;
@@ -204,15 +204,17 @@ namespace {
 __global__ void bf16_to_e4m3_kernel(const unsigned short* __restrict__ in, unsigned char* __restrict__ out, long n8) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
     float f[8];
-    unpack8(*(const u32x4*)(in + 8 * i), f);
-    *(u32x2*)(out + 8 * i) = e4m3x8_sat(f);
+    unpack8(ld_stream<u32x4>(in + 8 * i), f);
+    st_stream<u32x2>(out + 8 * i, e4m3x8_sat(f));
   }
 }
+// 8 elements per thread (16 per thread - one 16-byte load, two 16-byte stores 32 bytes apart - measured 11 % slower,
+// profiles/r04_stream_kernels_old_vs_new_lib.jsonl)
 template <bool ACTIVATE>
 __global__ void e4m3_to_bf16_kernel(const unsigned char* __restrict__ in, unsigned short* __restrict__ out, long n8, int act) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
     float f[8];
-    e4m3x8_to_f32(*(const u32x2*)(in + 8 * i), f);
+    e4m3x8_to_f32(ld_stream<u32x2>(in + 8 * i), f);
     if (ACTIVATE) {
 #pragma unroll
       for (int j = 0; j < 8; j += 2) {
@@ -222,10 +224,11 @@ __global__ void e4m3_to_bf16_kernel(const unsigned char* __restrict__ in, unsign
         f[j + 1] = r.y;
       }
     }
-    *(u32x4*)(out + 8 * i) = pack8(f);
+    st_stream<u32x4>(out + 8 * i, pack8(f));
   }
 }
-unsigned cast_grid(long n8) { const long b = (n8 + 255) / 256; return (unsigned)(b < 1 ? 1 : (b > 65536 ? 65536 : b)); }
+// one-shot: a thread per 8 elements (a persistent grid striding the array streams a third slower, tools/probes/stream_ab.hip)
+unsigned cast_grid(long n8) { const long b = (n8 + 255) / 256; return (unsigned)(b < 1 ? 1 : (b > 0x7fffffffL ? 0x7fffffffL : b)); }
 int cast_args(const char* what, const void* in, const void* out, int64_t n) {
   if (n % 8 != 0 || ((size_t)in & 7) || ((size_t)out & 7)) { clipa_set_error("%s: n must be a multiple of 8 and the buffers 8-byte aligned", what); return CLIPA_ERR_ARG; }
   return 0;

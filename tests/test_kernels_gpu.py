@@ -331,6 +331,29 @@ def test_layernorm(D, xdt, ydt):
     check("dx no-res", dx2, xr.grad, tolx, tolx * 4)
 
 
+@pytest.mark.parametrize("rows", [1, 41, 8190, 300001])
+def test_layernorm_row_counts(rows):
+    """The launch shapes of layernorm.hip: forward = one block per 8 rows (odd tails), backward = one block per C adjacent rows
+    (C = 4 ... 128 by row count) whose dgamma / dbeta partials go through the one- or two-pass reduction (<= / > 128 blocks)."""
+    D = 256
+    x = (rnd(rows, D, seed=25) * 1.5 + 0.3).to(bf16)
+    w, b = 1 + 0.1 * rnd(D, seed=26, dtype=f32), 0.1 * rnd(D, seed=27, dtype=f32)
+    dy, dres = rnd(rows, D, seed=28), rnd(rows, D, seed=29)
+    xr = x.double().requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = O.layer_norm(xr, wr, br)
+    yr.backward(dy.double())
+    y = ops().layernorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5, out_dtype=bf16)
+    check("fwd", y, yr, 2 ** -7, 2 ** -7)
+    dx, dw, db = ops().layernorm_bwd(x.to(DEV), w.to(DEV), dy.to(DEV), dres.to(DEV), 1e-5)
+    check("dx", dx, xr.grad + dres.double(), 2 ** -7, 2 ** -5)
+    scale = max(1.0, rows ** 0.5)              # the column sums grow like sqrt(rows); fp32 partials
+    check("dgamma", dw, wr.grad, 1e-4, 2e-3 * scale)
+    check("dbeta", db, br.grad, 1e-4, 2e-3 * scale)
+    dx2, dw2, db2 = ops().layernorm_bwd(x.to(DEV), w.to(DEV), dy.to(DEV), dres.to(DEV), 1e-5)
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2)      # fixed summation order
+
+
 # -------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dh", [64, 80])       # 80 = ViT-H/14 (head_width 80)
 @pytest.mark.parametrize("B,H,L,causal", [(2, 3, 26, False), (3, 2, 50, False), (2, 2, 77, True), (2, 4, 197, False),

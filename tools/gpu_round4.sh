@@ -33,6 +33,10 @@ for s in $STAGES; do
       timeout 600 python tools/gemm_lib_ab.py clipa_amd/lib/libclipa_hip.so $(ls clipa_amd/lib/libclipa_var_st*.so) > gpurun_out/store_policy_ab.jsonl 2>&1; echo "rc=$?" >> gpurun_out/store_policy_ab.jsonl ;;
     libab)
       timeout 600 python tools/gemm_lib_ab.py clipa_amd/lib/libclipa_hip.so ${LIBAB_LIBS} > gpurun_out/gemm_lib_ab.jsonl 2>&1; echo "rc=$?" >> gpurun_out/gemm_lib_ab.jsonl ;;
+    streamab)
+      # grid shape / cache policy sweep of the HBM-streaming kernels, then old-vs-new library (build both with the recipe in tools/stream_lib_ab.py)
+      timeout 200 ./tools/probes/stream_ab 806912 ${STREAMAB_PHASE:-2} > gpurun_out/stream_ab.jsonl 2>&1; echo "rc=$?" >> gpurun_out/stream_ab.jsonl
+      timeout 360 python tools/stream_lib_ab.py tools/probes/lnvar/libstream_old.so tools/probes/lnvar/libstream_new.so > gpurun_out/stream_lib_ab.jsonl 2>&1; echo "rc=$?" >> gpurun_out/stream_lib_ab.jsonl ;;
     tnab)
       timeout 600 ./tools/probes/gemm_tna_ab ${GEMMAB_ARGS:-} > gpurun_out/gemm_tna_ab.log 2>&1; echo "rc=$?" >> gpurun_out/gemm_tna_ab.log ;;
     fp8conv)
