@@ -50,12 +50,6 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
   return v;
 }
 
-// ---- streaming accesses ---------------------------------------------------------------------
-// Non-temporal 8 / 16-byte loads and stores for operands an HBM-bound kernel touches exactly once (row streams of the
-// LayerNorm / quantise / cast / re-materialise kernels): +4 % on a one-shot grid (tools/probes/stream_ab.hip).
-template <class V> __device__ __forceinline__ V ld_stream(const void* p) { return __builtin_nontemporal_load((const V*)p); }
-template <class V> __device__ __forceinline__ void st_stream(void* p, V v) { __builtin_nontemporal_store(v, (V*)p); }
-
 // ---- activations (transformer.py:37-40 QuickGELU, nn.GELU erf / tanh) ----------------------
 enum { ACT_GELU_ERF = 0, ACT_GELU_TANH = 1, ACT_QUICK_GELU = 2 };
 

@@ -2,6 +2,7 @@
 // Each cites the reference lines whose arithmetic it reproduces (paths relative to
 // /root/reference/clipa_torch).
 #include "common.h"
+#include "stream.h"
 #include "clipa_hip.h"
 
 namespace {

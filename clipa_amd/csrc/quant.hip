@@ -8,6 +8,7 @@
 // HBM-bound: one wave per row, the row stays in registers between the max and the convert (2 B read + 1 B written
 // per element); the LayerNorm variant emits the fp8 operand of the following GEMM straight from the normalised row.
 #include "common.h"
+#include "stream.h"
 #include "clipa_hip.h"
 
 namespace {
