@@ -9,7 +9,7 @@ STAGES="${*:-newtests benchq}"
 for s in $STAGES; do
   case $s in
     alltests)
-      timeout 1800 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -s > gpurun_out/pytest_gpu.log 2>&1
+      timeout 1800 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -s --durations=15 > gpurun_out/pytest_gpu.log 2>&1
       echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log ;;
     newtests)
       timeout 1200 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py tests/test_fp8_gpu.py -m gpu -q --tb=short -p no:cacheprovider -s \
