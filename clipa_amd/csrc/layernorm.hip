@@ -5,7 +5,8 @@
 // Grid shapes and cache policy follow tools/probes/stream_ab.hip (profiles/r04_stream_kernel_shapes_ab_*.jsonl, rows = 806912,
 // D = 1024): a ONE-SHOT grid (a block lives for 8 rows) streams at 6.1 TB/s where 2048 persistent blocks striding the rows
 // reach 4.7, and non-temporal loads + stores of the row streams are worth another 4 %; the backward kernel, which has to carry
-// dgamma / dbeta partials, gives every block 128 ADJACENT rows (5.4 TB/s including the partial reduction, 4.4 persistent).
+// dgamma / dbeta partials, gives every block 128 ADJACENT rows (5.4 TB/s including the partial reduction, 4.4 persistent)
+// - for rows of at most 1024 elements; wider rows stay on the persistent grid (ln_bwd_chunk).
 #include "common.h"
 #include "clipa_hip.h"
 
@@ -115,8 +116,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
-  // block b owns the C adjacent rows [b C, (b + 1) C); its four waves take them interleaved (one 4-row window per step)
-  const long row_end = rows < (long)(blockIdx.x + 1) * C ? rows : (long)(blockIdx.x + 1) * C;
+  // C > 0: block b owns the C adjacent rows [b C, (b + 1) C), its four waves take them interleaved (one 4-row window per step);
+  // C == 0: the rows are strided over all waves of a persistent grid
+  const long row_end = (C && rows > (long)(blockIdx.x + 1) * C) ? (long)(blockIdx.x + 1) * C : rows;
+  const long row_first = C ? (long)blockIdx.x * C + wv : (long)blockIdx.x * 4 + wv;
+  const long row_step = C ? 4 : (long)gridDim.x * 4;
   const int nchunks = D >> 3;
   float g[NCH][8], dg[NCH][8], db[NCH][8];
 #pragma unroll
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
     if (ch < nchunks) ld8<true, false>(gamma, (size_t)ch * 8, g[c]);
   }
   const float invD = 1.0f / (float)D;
-  for (long r = (long)blockIdx.x * C + wv; r < row_end; r += 4) {
+  for (long r = row_first; r < row_end; r += row_step) {
     float v[NCH][8], d[NCH][8];
     float s = 0.f;
 #pragma unroll
@@ -250,13 +254,21 @@ int ln_fwd_grid(long rows) {
   if (g < 1) g = 1;
   return (int)g;
 }
-// backward: rows per block - 128 where that still leaves >= 2048 blocks, fewer (a multiple of 4) for short inputs
+// backward: rows per block - 128 where that still leaves >= 2048 blocks, fewer (a multiple of 4) for short inputs.
+// Rows wider than 1024 (three or four 16-byte chunks per lane, ViT-H/14's 1280) keep the persistent 1024-block grid of rounds
+// 1-3 (chunk 0): at 526 336 x 1280 the 128-row blocks measured 3.5 % slower (profiles/r04_stream_kernels_old_vs_new_lib.jsonl).
 constexpr int LN_BWD_SLICES = 16;
-int ln_bwd_chunk(long rows) {
+int ln_bwd_chunk(long rows, long D) {
+  if (D > 1024) return 0;
   long c = (rows / 2048 + 3) / 4 * 4;
   return (int)(c < 4 ? 4 : (c > 128 ? 128 : c));
 }
-long ln_bwd_grid(long rows) { const long c = ln_bwd_chunk(rows); return (rows + c - 1) / c; }
+long ln_bwd_grid(long rows, long D) {
+  const long c = ln_bwd_chunk(rows, D);
+  if (c) return (rows + c - 1) / c;
+  const long g = (rows + 3) / 4;
+  return g > 1024 ? 1024 : g;
+}
 
 template <int NCH>
 void launch_fwd(const void* x, const float* g, const float* b, void* y, long rows, int D, float eps,
@@ -292,7 +304,7 @@ extern "C" int clipa_layernorm_fwd(const void* x, const float* gamma, const floa
 }
 
 extern "C" int64_t clipa_layernorm_bwd_workspace(int64_t rows, int64_t D) {
-  return (int64_t)2 * (ln_bwd_grid(rows) + LN_BWD_SLICES) * D * sizeof(float);   // [2][blocks][D] + [2][slices][D]
+  return (int64_t)2 * (ln_bwd_grid(rows, D) + LN_BWD_SLICES) * D * sizeof(float);   // [2][blocks][D] + [2][slices][D]
 }
 
 extern "C" int clipa_layernorm_bwd(const void* x, const float* gamma, const void* dy, const void* dres,
@@ -303,7 +315,7 @@ extern "C" int clipa_layernorm_bwd(const void* x, const float* gamma, const void
   if (rows <= 0) return CLIPA_OK;
   if (!workspace || workspace_bytes < clipa_layernorm_bwd_workspace(rows, D)) { clipa_set_error("layernorm_bwd: workspace too small"); return CLIPA_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
-  const int grid = (int)ln_bwd_grid(rows), C = ln_bwd_chunk(rows);
+  const int grid = (int)ln_bwd_grid(rows, D), C = ln_bwd_chunk(rows, D);
   float* part = (float*)workspace;
   if (D <= 512) launch_bwd<1>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, C, st);
   else if (D <= 1024) launch_bwd<2>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, C, st);

@@ -188,8 +188,14 @@ extern "C" int clipa_layernorm_fwd_q8(const void* x, const float* gamma, const f
                                       int64_t rows, int64_t D, float eps, void* stream) {
   if (rows <= 0) return CLIPA_OK;
   if (D <= 0 || D % 8 != 0 || D > 2048) { clipa_set_error("layernorm_fwd_q8: D=%ld must be a multiple of 8 in (0, 2048]", (long)D); return CLIPA_ERR_ARG; }
-  long blocks = (rows + 3) / 4;                    // one-shot grid, a wave per row (as layernorm.hip; the row loop is for > 2^33 rows)
-  if (blocks > 0x7fffffffL) blocks = 0x7fffffffL;
+  // 8192 blocks striding the rows: at 806 912 x 1024 / 526 336 x 1280 / 157 696 x 1280 the persistent 2048 blocks of rounds
+  // 2-3 take 0.827 / 0.733 / 0.221 ms, 8192 blocks 0.679 / 0.706 / 0.218, a one-shot grid 0.722 / 0.862 / 0.256 (gamma and
+  // beta are re-read by every wave: 4x the row bytes) - profiles/r04_stream_kernels_old_vs_new_lib.jsonl
+#ifndef LN_Q8_BLOCK_CAP
+#define LN_Q8_BLOCK_CAP 8192                      // A/B knob (tools/stream_lib_ab.py)
+#endif
+  long blocks = (rows + 3) / 4;
+  if (blocks > LN_Q8_BLOCK_CAP) blocks = LN_Q8_BLOCK_CAP;
   const dim3 grid((unsigned)blocks), block(256);
   hipStream_t st = (hipStream_t)stream;
   const char* xp = (const char*)x;

@@ -206,10 +206,9 @@ def test_fp8_linear_is_close_to_bf16_linear():
     assert bias_rel < 0.005, f"fp8 linear is biased: {bias_rel:.5f}"
 
 
-@pytest.mark.parametrize("D", [384, 768, 1024, 1280])
-def test_layernorm_fwd_q8(D):
+@pytest.mark.parametrize("D,rows", [(384, 1000), (768, 1000), (1024, 1000), (1280, 1000), (256, 40003)])   # 40003 rows: more than one pass of the 8192-block grid
+def test_layernorm_fwd_q8(D, rows):
     o = ops()
-    rows = 1000
     x = (rnd(rows, D, seed=D, dtype=f32) * 2.0 + 0.3).to(bf16).to(DEV)
     gamma = (1.0 + 0.1 * rnd(D, seed=1, dtype=f32)).to(DEV)
     beta = (0.1 * rnd(D, seed=2, dtype=f32)).to(DEV)

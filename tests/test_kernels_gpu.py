@@ -331,11 +331,11 @@ def test_layernorm(D, xdt, ydt):
     check("dx no-res", dx2, xr.grad, tolx, tolx * 4)
 
 
-@pytest.mark.parametrize("rows", [1, 41, 8190, 300001])
-def test_layernorm_row_counts(rows):
+@pytest.mark.parametrize("rows,D", [(1, 256), (41, 256), (8190, 256), (300001, 256), (9001, 1280)])
+def test_layernorm_row_counts(rows, D):
     """The launch shapes of layernorm.hip: forward = one block per 8 rows (odd tails), backward = one block per C adjacent rows
-    (C = 4 ... 128 by row count) whose dgamma / dbeta partials go through the one- or two-pass reduction (<= / > 128 blocks)."""
-    D = 256
+    (C = 4 ... 128 by row count) whose dgamma / dbeta partials go through the one- or two-pass reduction (<= / > 128 blocks);
+    rows wider than 1024 elements: the persistent 1024-block grid (more than one row per wave at 9001 rows)."""
     x = (rnd(rows, D, seed=25) * 1.5 + 0.3).to(bf16)
     w, b = 1 + 0.1 * rnd(D, seed=26, dtype=f32), 0.1 * rnd(D, seed=27, dtype=f32)
     dy, dres = rnd(rows, D, seed=28), rnd(rows, D, seed=29)
