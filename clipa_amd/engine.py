@@ -198,13 +198,15 @@ def _block_backward(x, dy, box, P, cfg):
     elif g is None:      # "light" block: cheap HBM-bound re-materialisation instead of 4 GEMMs + attention
         g = ops.activation_fwd(hpre, act)
         h2 = ops.layernorm_fwd(x1, P["ln2_w"], P["ln2_b"], cfg["eps"])
-    # y = x1 + c_proj(g)
+    # y = x1 + c_proj(g).  The weight gradient goes first: g ([M, 4D], the largest transient of the block) is released before
+    # the GELU-backward GEMM allocates its output of the same size
+    d_w_proj, d_b_proj = ops.gemm_tn(dy, g, P["dt_w_proj"], want_colsum=True)
+    del g
     if fp8:
         dh = _dlin8(dy, P, "proj", cfg, epi=ops.EPI_DACT, act=act, aux=hpre)
     else:
         dh = ops.gemm_nt(dy, P["wt_proj"], epi=ops.EPI_DACT, act=act, aux=hpre)     # [M,4D]
-    d_w_proj, d_b_proj = ops.gemm_tn(dy, g, P["dt_w_proj"], want_colsum=True)
-    del g, hpre
+    del hpre
     dh2 = _dlin8(dh, P, "fc", cfg) if fp8 else ops.gemm_nt(dh, P["wt_fc"])       # [M,D]
     d_w_fc, d_b_fc = ops.gemm_tn(dh, h2, P["dt_w_fc"], want_colsum=True)
     del dh, h2
