@@ -154,7 +154,8 @@ class Transformer(nn.Module):
         # per token): no GEMM is re-run, gelu'(h) and the re-materialised activation come from the rounded value
         # (engine._block_forward).  Order of the tiers along the depth: light, light8, medium, recompute.
         self.light8_blocks = 0
-        # ... or tensor by tensor (bf16 engines; what bench.py's planner uses): the first keep_counts[t] blocks keep tensor t
+        # ... or tensor by tensor (bf16 engines; what bench.py's planner uses): the LAST keep_counts[t] blocks keep tensor t (their
+        # backward runs first, at the memory peak: the blocks that recompute do so after kept tensors have been released)
         # ("h8" e4m3 pre-activation, "a" attention output + statistics, "x1", "qkv"), on top of the named tiers above
         self.keep_counts = {"h8": 0, "a": 0, "x1": 0, "qkv": 0}
         # fp8 engine mode (create_model(precision="fp8"), BASELINE.json configs[3]): the four linear layers of every block run
@@ -182,7 +183,7 @@ class Transformer(nn.Module):
         for i, blk in enumerate(self.resblocks):
             cfg = kept if i < n1 else (light8 if i < n2 else (medium if i < n2 + self.medium_blocks else base))
             if counted:
-                ks = frozenset(t for t, n in self.keep_counts.items() if i < n) | engine.KEEP_SETS.get(cfg["keep"] if cfg is not base else None, frozenset())
+                ks = frozenset(t for t, n in self.keep_counts.items() if i >= len(self.resblocks) - n) | engine.KEEP_SETS.get(cfg["keep"] if cfg is not base else None, frozenset())
                 if ks:
                     cfg = dict(base, keep_this=True, keep=ks)
             if i == last and pooled_rows is not None and not self.fp8:
