@@ -62,6 +62,20 @@ def train_gflop_per_pair(cfg, S, ctx):
     return 3.0 * fwd / 1e9
 
 
+def pruned_gflop_per_pair(cfg, S, ctx, image_pruned, text_pruned):
+    """Model FLOPs of `train_gflop_per_pair` that the engine does NOT execute: the out-projection + MLP of a tower's LAST block
+    on the rows its head never reads (engine.LastBlockFn: class-token / EOT pooling; forward, input gradient and weight gradient
+    = 3 x 18 D^2 per dead token).  ViT-L/16 @ 224 + text-77: 11.1 + 2.4 GF of 409.2."""
+    v, t = cfg["vision_cfg"], cfg["text_cfg"]
+    g = S // v["patch_size"]
+    dead = 0.0
+    if image_pruned:
+        dead += (g * g) * 18 * v["width"] ** 2
+    if text_pruned:
+        dead += (ctx - 1) * 18 * t["width"] ** 2
+    return 3.0 * dead / 1e9
+
+
 def kernel_entry(v, steps):
     """One line of the `kernels` block: MFMA-bound kernels (algorithmic FLOPs known) report TFLOP/s, HBM-bound ones (LayerNorm,
     row quantisers, patch gather, activation re-materialisation, crops) their algorithmic bytes per second and the fraction
@@ -97,15 +111,26 @@ KEEP_VALUE_MS_PER_GB = (("v", "h8", 1.5), ("t", "h8", 1.13), ("v", "a", 0.94), (
                         ("v", "qkv", 0.79), ("t", "a", 0.70), ("t", "qkv", 0.66))
 
 
-def plan_keep_tensors(budget, layers, nbytes):
-    """Greedy per-tensor plan for the bf16 engines: walk KEEP_VALUE_MS_PER_GB, give each (tower, tensor) as many blocks as the
-    budget still holds.  layers: {"v": n, "t": n}; nbytes: {(tower, tensor): bytes per block}.  -> {tower: {tensor: blocks}}."""
+# The same order without the e4m3 pre-activation: every tensor of this list is kept bit for bit (bf16 as the forward wrote it), so
+# the step's gradients are those of the all-recompute step bit for bit (`value_exact_tiers`); the bf16 pre-activation ("h", twice
+# the bytes of "h8" for the same saved GEMM) ranks below qkv.
+KEEP_VALUE_MS_PER_GB_EXACT = (("v", "a", 0.94), ("v", "x1", 0.91), ("t", "x1", 0.88), ("v", "qkv", 0.79), ("v", "h", 0.75),
+                              ("t", "a", 0.70), ("t", "qkv", 0.66), ("t", "h", 0.57))
+
+
+def plan_keep_tensors(budget, layers, nbytes, order=KEEP_VALUE_MS_PER_GB, pruned_last=()):
+    """Greedy per-tensor plan for the bf16 engines: walk `order`, give each (tower, tensor) as many blocks as the budget still
+    holds.  layers: {"v": n, "t": n}; nbytes: {(tower, tensor): bytes per block}; pruned_last: towers whose LAST block runs its
+    out-projection / MLP on the pooled rows only (engine.LastBlockFn) - keep_counts gives a tensor to the LAST n blocks, so the
+    first block of an "x1" / "h8" / "h" count is that one and holds a few MB instead of a token-level tensor.
+    -> {tower: {tensor: blocks}}."""
     budget = max(0, int(budget))
-    plan = {tw: {"h8": 0, "a": 0, "x1": 0, "qkv": 0} for tw in layers}
-    for tw, name, _ in KEEP_VALUE_MS_PER_GB:
-        n = min(layers[tw], budget // nbytes[(tw, name)])
+    plan = {tw: {"h8": 0, "h": 0, "a": 0, "x1": 0, "qkv": 0} for tw in layers}
+    for tw, name, _ in order:
+        free = 1 if (tw in pruned_last and name in ("x1", "h8", "h")) else 0
+        n = min(layers[tw], free + budget // nbytes[(tw, name)])
         plan[tw][name] = int(n)
-        budget -= n * nbytes[(tw, name)]
+        budget -= max(0, n - free) * nbytes[(tw, name)]
     return plan
 
 
@@ -183,7 +208,16 @@ def main():
     ap.add_argument("--tier-plan", action="store_true",
                     help="plan whole tiers (medium, then light8 upgrades) instead of tensor by tensor (the round-4 default for bf16)")
     ap.add_argument("--no-light8", action="store_true",
-                    help="upgrade medium-kept blocks to the bf16 'light' tier instead of 'light8' (e4m3 pre-activations)")
+                    help="keep bit-exact tensors only: no e4m3 pre-activation (per-tensor plan: the bf16 pre-activation ranks below "
+                         "qkv; --tier-plan: the bf16 'light' tier instead of 'light8').  The default run reports this plan's rate as "
+                         "`value_exact_tiers` next to `value`")
+    ap.add_argument("--exact-steps", type=int, default=3,
+                    help="extra steps after the timed region under the keep plan restricted to bit-exact tensors (same budget, no e4m3 "
+                         "pre-activation): reported as `value_exact_tiers`, never part of `value` (0 = skip)")
+    ap.add_argument("--no-second-pass", action="store_true",
+                    help="skip the second planning pass (spend only the budget derived from the all-recompute step's peak)")
+    ap.add_argument("--second-pass-fraction", type=float, default=0.8,
+                    help="share of the device memory still free after the planned trial step that the second planning pass may spend")
     ap.add_argument("--unpad-text", action="store_true",
                     help="run the TIMED region with the engine's unpad_text knob (causal text tower on the tokens up to each caption's "
                          "EOT only; identical features / loss / gradients).  Off by default: `value` is measured on the reference's "
@@ -275,10 +309,22 @@ def main():
         print(f"bench.py: --batch {B} is not a multiple of --accum-freq {A}", file=sys.stderr)
         sys.exit(2)
 
+    lens_cache = {}
+
+    def host_lengths(tx):
+        """unpad_text: the caption lengths as the loader's host side knows them (read back ONCE per resident batch here) - the
+        engine then needs no device-to-host copy inside the step."""
+        if not model.unpad_text:
+            return None
+        key = (tx.data_ptr(), tx.shape[0])
+        if key not in lens_cache:
+            lens_cache[key] = (tx.argmax(-1) + 1).cpu()
+        return lens_cache[key]
+
     def step(images=images, texts=texts):
         opt.zero_grad(set_to_none=True)                        # (the sharded optimizer zeroes its flat buffers instead)
         if A == 1:
-            out = step_model(images, texts)
+            out = step_model(images, texts, text_lengths=host_lengths(texts))
             loss = loss_fn(**out, output_dict=True)["contrastive_loss"]
             loss.backward()
         else:
@@ -288,7 +334,7 @@ def main():
             feats = {"image_features": [], "text_features": []}
             with torch.no_grad():
                 for im, tx in chunks:
-                    o = step_model(im, tx)
+                    o = step_model(im, tx, text_lengths=host_lengths(tx))
                     for k in feats:
                         feats[k].append(o[k])
             import contextlib
@@ -298,7 +344,7 @@ def main():
                 defer = contextlib.nullcontext() if (j == A - 1 or not dist_on) else \
                     (opt.no_sync() if args.optimizer == "sharded" else step_model.no_sync())
                 with defer:
-                    o = step_model(im, tx)
+                    o = step_model(im, tx, text_lengths=host_lengths(tx))
                     scale = o.pop("logit_scale")
                     inputs = {k: torch.cat(v[:j] + [o[k]] + v[j + 1:]) for k, v in feats.items()}
                     loss = loss_fn(**inputs, logit_scale=scale, output_dict=True)["contrastive_loss"]
@@ -327,7 +373,7 @@ def main():
             vtr.keep_blocks = ttr.keep_blocks = vtr.light8_blocks = ttr.light8_blocks = vtr.medium_blocks = ttr.medium_blocks = 0
             vtr.keep_counts, ttr.keep_counts = dict(tensor_plan["v"]), dict(tensor_plan["t"])
             return
-        vtr.keep_counts, ttr.keep_counts = ({"h8": 0, "a": 0, "x1": 0, "qkv": 0} for _ in range(2))
+        vtr.keep_counts, ttr.keep_counts = ({"h8": 0, "h": 0, "a": 0, "x1": 0, "qkv": 0} for _ in range(2))
         if use_l8:
             vtr.light8_blocks, ttr.light8_blocks, vtr.keep_blocks, ttr.keep_blocks = kv, kt, 0, 0
         else:
@@ -336,11 +382,19 @@ def main():
 
     keep_v = keep_t = med_v = med_t = 0
     backoffs = 0
+    second_pass = None                  # what the second planning pass (from the planned step's own free HBM) added, bytes
+    exact_plan_fn = None                # budget -> plan restricted to bit-exact tensors (for `value_exact_tiers`)
+    final_budget = None
     L_img = (args.image_size // cfg["vision_cfg"]["patch_size"]) ** 2 + 1
     vt, tt = model.visual.transformer, model.transformer
+    layers = {"v": cfg["vision_cfg"]["layers"], "t": cfg["text_cfg"]["layers"]}
+    # towers whose last block runs on the pooled rows only (engine.LastBlockFn; bf16 engines): class-token image towers, text
+    image_pruned = args.precision != "fp8" and model.visual._pool_mode() == ops.POOL_FIRST
+    text_pruned = args.precision != "fp8"
+    pruned_last = tuple(tw for tw, on in (("v", image_pruned), ("t", text_pruned)) if on)
     warm = args.warmup
+    total_mem = torch.cuda.get_device_properties(dev).total_memory
     if args.keep_blocks == "auto":
-        total_mem = torch.cuda.get_device_properties(dev).total_memory
         torch.cuda.reset_peak_memory_stats(dev)
         step()                                   # one extra untimed all-recompute step, only to measure its peak
         torch.cuda.synchronize()                 # (under DDP this peak already contains the reducer's buckets)
@@ -357,18 +411,19 @@ def main():
         lv_b, lt_b = (vt.light8_keep_bytes(B // A * L_img), tt.light8_keep_bytes(B // A * args.ctx)) if use_l8 else \
             (vt.light_keep_bytes(B // A * L_img), tt.light_keep_bytes(B // A * args.ctx))
 
-        per_tensor = use_l8 and not args.tier_plan
+        per_tensor = args.precision != "fp8" and not args.tier_plan
         tok_v, tok_t = B // A * L_img, B // A * args.ctx
-        tb = {(tw, n): tr.tensor_keep_bytes(tok, n) for tw, tr, tok in (("v", vt, tok_v), ("t", tt, tok_t)) for n in ("h8", "a", "x1", "qkv")}
+        tb = {(tw, n): tr.tensor_keep_bytes(tok, n) for tw, tr, tok in (("v", vt, tok_v), ("t", tt, tok_t)) for n in ("h8", "h", "a", "x1", "qkv")}
+        order = KEEP_VALUE_MS_PER_GB if use_l8 else KEEP_VALUE_MS_PER_GB_EXACT
+        if per_tensor:
+            exact_plan_fn = lambda budget: plan_keep_tensors(budget, layers, tb, KEEP_VALUE_MS_PER_GB_EXACT, pruned_last)
 
         def plan(budget):
             nonlocal tensor_plan
             if per_tensor:
-                tensor_plan = plan_keep_tensors(budget, {"v": cfg["vision_cfg"]["layers"], "t": cfg["text_cfg"]["layers"]}, tb)
+                tensor_plan = plan_keep_tensors(budget, layers, tb, order, pruned_last)
                 return 0, 0, 0, 0
-            return plan_keep(budget, cfg["vision_cfg"]["layers"], cfg["text_cfg"]["layers"], mv_b, mt_b, lv_b, lt_b)
-
-        keep_v, keep_t, med_v, med_t = plan(budget0)
+            return plan_keep(budget, layers["v"], layers["t"], mv_b, mt_b, lv_b, lt_b)
 
         # Trial step under the plan; an allocator-fragmentation OOM shrinks the budget instead of failing the run.  With
         # several ranks a rank must never run out of memory INSIDE a collective (its peers would wait for it forever), so
@@ -394,8 +449,10 @@ def main():
                 model._gather_partner = partner
                 opt.zero_grad(set_to_none=True)
 
-        backoffs = 0
-        for attempt in range(5):
+        def fits(budget):
+            """Plan `budget`, run the trial step under it -> True if every rank got through."""
+            nonlocal keep_v, keep_t, med_v, med_t
+            keep_v, keep_t, med_v, med_t = plan(budget)
             set_keep(keep_v, keep_t, med_v, med_t)
             ok = 1
             try:
@@ -408,14 +465,40 @@ def main():
                 vote = torch.tensor([ok], device=dev, dtype=torch.int32)
                 dist.all_reduce(vote, op=dist.ReduceOp.MIN)
                 ok = int(vote.item())
-            if ok:
+            return bool(ok)
+
+        backoffs = 0
+        for attempt in range(5):
+            if fits(budget0):
+                final_budget = budget0
                 break
             backoffs += 1
             budget0 -= 12 << 30
-            keep_v, keep_t, med_v, med_t = plan(budget0)
-        else:
+        if final_budget is None:
             keep_v = keep_t = med_v = med_t = 0        # five plans did not fit: fall back to the all-recompute step that did
             tensor_plan = None
+        elif not args.no_second_pass:
+            # Second planning pass (the budget above comes from the ALL-RECOMPUTE step's peak, whose per-block transients
+            # are about twice the planned step's): what the device still has free after the trial step of the plan - memory no
+            # allocator segment covers - goes to the planner too, less a margin; one more trial decides, and a plan that does not
+            # fit is taken back (the first plan is re-run, so the allocator is in the state the timed region will find).
+            free_dev, _ = torch.cuda.mem_get_info(dev)
+            extra = int(args.second_pass_fraction * free_dev) - (2 << 30)
+            if dist_on:
+                extra = agree_budget(extra, dev)
+            snapshot = lambda t4: (tuple(int(v) for v in t4), json.dumps(tensor_plan, sort_keys=True))
+            before = snapshot((keep_v, keep_t, med_v, med_t))
+            changed = extra > 0 and snapshot(plan(final_budget + extra)) != before
+            if changed and fits(final_budget + extra):
+                second_pass = extra
+                final_budget += extra
+            elif changed:
+                backoffs += 1
+                if not fits(final_budget):             # (cannot happen short of fragmentation: it fitted a moment ago)
+                    keep_v = keep_t = med_v = med_t = 0
+                    tensor_plan, final_budget = None, None
+            else:
+                keep_v, keep_t, med_v, med_t = plan(final_budget)
     else:
         vals = [int(v) for v in args.keep_blocks.split(",")]
         keep_v, keep_t = vals[0], vals[1]
@@ -459,12 +542,43 @@ def main():
             ep = float(tm)
         plain_ms = round(1e3 * ep / args.plain_steps, 2)
 
+    # The same step under the keep plan restricted to BIT-EXACT tensors (no e4m3 pre-activation; VERDICT r4 next #1c): its
+    # gradients are those of the all-recompute bf16 step bit for bit (tests/test_model_gpu.py::
+    # test_headline_configuration_matches_oracle), where the default plan's carry the e4m3 rounding of the kept pre-activations
+    # (cosine >= 0.995 against them, the engine's stated 0.99 against the fp32 oracle - same test).  Same activation budget less
+    # 8 GiB: a block that re-runs c_fc holds its bf16 pre-activation and the GELU output together.  Never part of `value`.
+    exact = None
+    if args.exact_steps > 0 and exact_plan_fn is not None and use_l8 and tensor_plan is not None and final_budget is not None \
+            and not dist_on:
+        default_plan = tensor_plan
+        try:
+            tensor_plan = exact_plan_fn(final_budget - (8 << 30))
+            set_keep(0, 0)
+            step()                                                           # warm-up: the allocator re-shapes its segments
+            fence()
+            te = time.perf_counter()
+            for _ in range(args.exact_steps):
+                loss_e = step()
+            fence()
+            ee = time.perf_counter() - te
+            exact = {"value": round(B * world * args.exact_steps / ee, 2), "unit": "pairs/s", "ms_per_step": round(1e3 * ee / args.exact_steps, 2),
+                     "steps": args.exact_steps, "loss": round(float(loss_e), 4),
+                     "plan": "kept tensors (image/text blocks) " + ", ".join(f"{n} {tensor_plan['v'][n]}/{tensor_plan['t'][n]}" for n in ("a", "x1", "qkv", "h")),
+                     "note": "keep plan restricted to bit-exact tensors (bf16 as the forward wrote them; no e4m3 pre-activation): "
+                             "gradients identical to the all-recompute bf16 step"}
+        except (RuntimeError, torch.OutOfMemoryError) as e:
+            opt.zero_grad(set_to_none=True)
+            exact = {"value": None, "error": str(e)[:200]}
+        tensor_plan = default_plan
+        torch.cuda.empty_cache()
+        set_keep(0, 0)
+
     # The engine's unpad_text knob: same inputs, same features / loss / gradients, the causal text tower on the
     # tokens up to each caption's EOT (SURVEY 8d's caption lengths ~ N(20, 8): about a quarter of the 77 positions).  Never
     # part of `value`, which stays on the reference's schedule unless --unpad-text asks otherwise.
     unpad = None
     # (single process only: toggling the knob changes the autograd graph, which DistributedDataParallel(static_graph=True) forbids)
-    if args.unpad_steps > 0 and not args.unpad_text and A == 1 and not dist_on:
+    if args.unpad_steps > 0 and not args.unpad_text and not dist_on:
         model.unpad_text = True
         try:
             step()                                                           # warm-up (allocator, index structures)
@@ -539,6 +653,8 @@ def main():
         ms = 1e3 * elapsed / args.steps
         pairs_s = B * world * args.steps / elapsed
         gf = train_gflop_per_pair(cfg, args.image_size, args.ctx)
+        gf_pruned = pruned_gflop_per_pair(cfg, args.image_size, args.ctx, image_pruned, text_pruned)
+        mfu_peak = PEAK_FP8_TFLOPS if args.precision == "fp8" else PEAK_BF16_TFLOPS
         # roofline of the DOMINANT kernel of this step (most time among the MFMA-bound GEMMs; gemm_nt for the bf16 headline)
         dom = max(ROOFLINE_KERNELS, key=lambda k: prof.get(k, {}).get("ms", 0.0))
         if args.precision != "fp8":
@@ -574,13 +690,19 @@ def main():
             "config": {"workload": f"{args.model}@{args.image_size} + text-{args.ctx}, local batch {B}, "
                                    f"global batch {B * world}, " + (f"accum_freq {A} (feature cache: +1 forward per pair), " if A > 1 else "") +
                                    f"InfoNCE local_loss+gather_with_grad, AdamW, " + ("text tower on the tokens up to EOT (unpad_text), " if args.unpad_text else "") +
-                                   ("block recompute except kept tensors (image/text blocks) " + ", ".join(f"{n} {tensor_plan['v'][n]}/{tensor_plan['t'][n]}" for n in ("h8", "a", "x1", "qkv")) if tensor_plan is not None else f"block recompute except {int(keep_v)}+{int(keep_t)} {'light8' if use_l8 else 'light'}-kept and {int(med_v)}+{int(med_t)} medium-kept (image+text) blocks"), "precision": args.precision, "parallelism": f"dp{world}" + ("" if args.optimizer == "adamw" else f" zero1/{args.exchange}"),
+                                   ("block recompute except kept tensors (image/text blocks) " + ", ".join(f"{n} {tensor_plan['v'][n]}/{tensor_plan['t'][n]}" for n in (("h8",) if use_l8 else ()) + ("a", "x1", "qkv") + (() if use_l8 else ("h",))) if tensor_plan is not None else f"block recompute except {int(keep_v)}+{int(keep_t)} {'light8' if use_l8 else 'light'}-kept and {int(med_v)}+{int(med_t)} medium-kept (image+text) blocks"), "precision": args.precision, "parallelism": f"dp{world}" + ("" if args.optimizer == "adamw" else f" zero1/{args.exchange}"),
                        "global_batch": B * world, "train_gflop_per_pair": round(gf, 2)},
-            "model_flops_util": round(pairs_s / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4),
+            # executed model FLOPs (the reference count less the dead rows of the pruned last blocks) against the peak of the
+            # precision the block GEMMs run in; `mfu_reference_flops` = the same rate priced at the reference's FLOP count
+            "model_flops_util": round(pairs_s / world * (gf - gf_pruned) / 1e3 / mfu_peak, 4),
+            "mfu_reference_flops": round(pairs_s / world * gf / 1e3 / mfu_peak, 4),
+            "mfu_peak_tflops": mfu_peak, "executed_gflop_per_pair": round(gf - gf_pruned, 2),
             "alloc_conf": args.alloc_conf, "loss": round(last_loss, 4), "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
             "peak_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2**30, 1),
             "alloc_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)),
             "keep_plan_backoffs": backoffs,
+            "keep_plan_second_pass_gb": None if second_pass is None else round(second_pass / 2**30, 1),
+            "total_hbm_gb": round(total_mem / 2**30, 1),
             # what the step spends outside this library's kernels (rank 0): at one rank host gaps + optimizer glue, with several
             # ranks additionally the EXPOSED part of the exchanges (gradient all-reduce tail, feature gathers); the wait of
             # the compute stream for the feature gathers is event-timed separately (per_rank.gather_wait_ms_per_step)
@@ -591,6 +713,7 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": round(nt.get("bytes", 0.0) / max(nt["launches"], 1)),
                          "launches": nt["launches"],
                          "avg_launch_ms": round(nt["ms"] / max(nt["launches"], 1), 4)},
+            "value_exact_tiers": exact,
             "h2d_inclusive": h2d,
             "unpadded_text": unpad,
             "kernels": {k: kernel_entry(v, args.steps) for k, v in prof.items() if "|" not in k},

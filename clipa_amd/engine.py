@@ -295,8 +295,13 @@ class LastBlockFn(torch.autograd.Function):
     def forward(ctx, x, rows, cfg, cache, *params):
         P = _block_operands(params, cache, False)
         needs_grad = any(ctx.needs_input_grad)
-        keep = needs_grad and (not cfg["recompute"] or cfg.get("keep_this", False))
-        qkv, a, stats = LastBlockFn._tokens(x, P, cfg, keep)
+        # token-level tensors this block keeps: the block's keep set like any other block's ("qkv", "a" = attention output +
+        # softmax statistics; the named tiers all hold both); x1 / the pre-activation exist for the B pooled rows only
+        ks = frozenset()
+        if needs_grad and (not cfg["recompute"] or cfg.get("keep_this", False)):
+            keep = cfg.get("keep", "light")
+            ks = KEEP_SETS.get(keep, keep) if isinstance(keep, (str, frozenset)) else KEEP_SETS["light"]
+        qkv, a, stats = LastBlockFn._tokens(x, P, cfg, "a" in ks)
         a_c, x_c = ops.gather_rows(a, rows), ops.gather_rows(x, rows)
         x1 = ops.gemm_nt(a_c, P["w_out"], P["b_out"], epi=ops.EPI_ADD, aux=x_c)
         h2 = ops.layernorm_fwd(x1, P["ln2_w"], P["ln2_b"], cfg["eps"])
@@ -305,14 +310,18 @@ class LastBlockFn(torch.autograd.Function):
         ctx.cfg, ctx.cache, ctx.params = cfg, cache, params
         if needs_grad:
             ctx.save_for_backward(x, rows)
-            ctx.tokens = (qkv, a, stats) if keep else None
+            ctx.tokens = (qkv if "qkv" in ks else None, a if "a" in ks else None, stats if "a" in ks else None)
             ctx.small = (a_c, x1, h2, hpre, g)
         return y
 
     @staticmethod
-    def _tokens(x, P, cfg, want_stats):
-        h1 = ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"])
-        qkv = ops.gemm_nt(h1, P["w_in"], P["b_in"])
+    def _qkv(x, P, cfg):
+        return ops.gemm_nt(ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"]), P["w_in"], P["b_in"])
+
+    @staticmethod
+    def _tokens(x, P, cfg, want_stats, qkv=None):
+        if qkv is None:
+            qkv = LastBlockFn._qkv(x, P, cfg)
         a, stats = _attn_fwd(qkv, cfg, bool(want_stats))
         return qkv, a, stats
 
@@ -332,8 +341,10 @@ class LastBlockFn(torch.autograd.Function):
         dx1, d_ln2_w, d_ln2_b = ops.layernorm_bwd(x1, P["ln2_w"], dh2, dres=dy, eps=cfg["eps"])
         da_c = ops.gemm_nt(dx1, P["wt_out"])
         d_w_out, d_b_out = ops.gemm_tn(dx1, a_c, P["dt_w_out"], want_colsum=True)
-        tok, ctx.tokens = ctx.tokens, None
-        qkv, a, stats = tok if tok is not None else LastBlockFn._tokens(x, P, cfg, True)
+        (qkv, a, stats), ctx.tokens = ctx.tokens, None
+        if qkv is None or a is None:      # whatever the block did not keep is recomputed bit for bit
+            qkv, a2, stats2 = LastBlockFn._tokens(x, P, cfg, True, qkv=qkv) if a is None else (LastBlockFn._qkv(x, P, cfg), a, stats)
+            a, stats = a2, stats2
         dqkv = _attn_bwd(qkv, a, ops.scatter_rows(da_c, rows, M), stats, cfg)
         del qkv, a, stats
         dh1 = ops.gemm_nt(dqkv, P["wt_in"])

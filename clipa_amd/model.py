@@ -156,8 +156,9 @@ class Transformer(nn.Module):
         self.light8_blocks = 0
         # ... or tensor by tensor (bf16 engines; what bench.py's planner uses): the LAST keep_counts[t] blocks keep tensor t (their
         # backward runs first, at the memory peak: the blocks that recompute do so after kept tensors have been released)
-        # ("h8" e4m3 pre-activation, "a" attention output + statistics, "x1", "qkv"), on top of the named tiers above
-        self.keep_counts = {"h8": 0, "a": 0, "x1": 0, "qkv": 0}
+        # ("h8" e4m3 pre-activation - or "h", the same tensor in bf16: twice the bytes, bit-exact gradients -, "a" attention
+        # output + statistics, "x1", "qkv"), on top of the named tiers above
+        self.keep_counts = {"h8": 0, "h": 0, "a": 0, "x1": 0, "qkv": 0}
         # fp8 engine mode (create_model(precision="fp8"), BASELINE.json configs[3]): the four linear layers of every block run
         # forward and input-gradient GEMMs on e4m3 operands (engine._block_forward_fp8); "e5m2" switches the gradient operand
         self.fp8 = False
@@ -192,11 +193,12 @@ class Transformer(nn.Module):
         return x if pooled_rows is None else engine.TokenDropFn.apply(x, pooled_rows)
 
     def light_keep_bytes(self, tokens):
-        """HBM bytes one kept block holds between forward and backward for `tokens` rows."""
-        return tokens * 9 * self.width * 2 + tokens * self.heads * 8   # qkv, a, x1, hpre (bf16) + softmax stats
+        """HBM bytes one kept block holds between forward and backward for `tokens` rows: qkv, a, x1, hpre (bf16) + softmax
+        statistics.  (The MLP width is the c_fc layer's own: 4.36 / 4.92 / 8.57 widths at ViT-g / bigG / e-14, not 4.)"""
+        return self.medium_keep_bytes(tokens) + self.tensor_keep_bytes(tokens, "h")
 
     def light8_keep_bytes(self, tokens):
-        return tokens * 7 * self.width * 2 + tokens * self.heads * 8   # qkv, a, x1 (bf16), hpre (e4m3: 4 * width bytes) + stats
+        return self.medium_keep_bytes(tokens) + self.tensor_keep_bytes(tokens, "h8")     # hpre as e4m3: one byte per element
 
     def tensor_keep_bytes(self, tokens, name):
         """HBM bytes of one kept tensor of one block (keep_counts)."""
@@ -341,7 +343,10 @@ class CLIP(nn.Module):
             _unsupported("HF text towers / embed_cls")
         self._cache = engine.WeightCache()
         self._gather_partner = None          # weakref to a ClipLoss that opted in with loss.bind(model)
-        self.unpad_text = False              # engine knob: run the causal text tower on the tokens up to each caption's EOT only
+        # engine knob: run the causal text tower on the tokens up to each caption's EOT only.  Set it BEFORE the first iteration
+        # under DistributedDataParallel(static_graph=True) (it changes the autograd graph); pass the caption lengths from the
+        # loader (`forward(image, text, text_lengths=...)`, a CPU tensor) to avoid a device-to-host read per step
+        self.unpad_text = False
         self.visual = VisionTransformer(
             image_size=vision_cfg.image_size, patch_size=vision_cfg.patch_size, width=vision_cfg.width,
             layers=vision_cfg.layers, heads=vision_cfg.width // vision_cfg.head_width, mlp_ratio=vision_cfg.mlp_ratio,
@@ -403,15 +408,24 @@ class CLIP(nn.Module):
         features = self.visual(image)
         return engine.L2NormFn.apply(features) if normalize else features
 
-    def _text_varlen(self, text):
+    def _text_varlen(self, text, text_lengths=None):
         """The index structure of the unpadded text tower (engine knob `unpad_text`), or None.  It needs the caption lengths on
-        the host (B integers): `forward` asks for them BEFORE the image tower is enqueued, so the copy waits for nothing."""
+        the host (B integers).  `text_lengths` (CPU integer tensor [B], position of the EOT token + 1 - the loader has the token
+        ids on the host anyway) costs nothing; without it the lengths are read back from the device, a blocking copy on the
+        compute stream: the host then waits until everything enqueued so far (the previous step's backward and optimizer) has
+        drained and loses its launch run-ahead once per step - `forward` at least asks before the image tower is
+        enqueued."""
         if not (self.unpad_text and self.causal and self.pool_style == 'open_clip'):
             return None
+        if text_lengths is not None:
+            lens = torch.as_tensor(text_lengths).to(torch.int64).cpu()
+            if lens.shape != (text.shape[0],) or int(lens.min()) < 1 or int(lens.max()) > text.shape[1]:
+                raise RuntimeError(f"text_lengths must be [B] integers in [1, {text.shape[1]}]")
+            return ops.VarLen(lens, text.shape[1], text.device)
         eot = ops.argmax_tokens(text.long())
         return ops.VarLen(eot.to(torch.int64).cpu() + 1, text.shape[1], text.device)
 
-    def encode_text(self, text, normalize: bool = False, _varlen=None):
+    def encode_text(self, text, normalize: bool = False, _varlen=None, text_lengths=None):
         if text.dim() != 2 or text.shape[1] != self.positional_embedding.shape[0]:
             raise RuntimeError(f"expected token ids [B,{self.positional_embedding.shape[0]}], got {tuple(text.shape)}")
         text = text.long()
@@ -422,7 +436,7 @@ class CLIP(nn.Module):
             # position after a caption's EOT can reach the pooled row x[arange, text.argmax(-1)] (model.py:251-254) or receive
             # gradient, so the tower runs on the tokens up to EOT only, packed back to back (zero-padded to whole GEMM tiles).
             # The lengths come to the host once per forward (B integers) to build the index structure.
-            vl = _varlen if _varlen is not None else self._text_varlen(text)
+            vl = _varlen if _varlen is not None else self._text_varlen(text, text_lengths)
             xp = engine.TokenDropFn.apply(x0, vl.src_rows)
             pooled = self.transformer.run(xp, B, T, True, self._cache, varlen=vl, pooled_rows=vl.last_rows)
             hcfg = {"B": B, "L": 1, "mode": ops.POOL_FIRST, "eps": 1e-5}
@@ -443,11 +457,11 @@ class CLIP(nn.Module):
                                        self.text_projection)
         return engine.L2NormFn.apply(features) if normalize else features
 
-    def forward(self, image, text):
+    def forward(self, image, text, text_lengths=None):
         # the reference trainer runs the model under torch.autocast(bfloat16) (train.py:160,203-205; precision.py:6-14):
         # every FLOP here is a HIP kernel with its own fixed operand types, so autocast is switched off for the glue
         with torch.autocast(device_type=image.device.type, enabled=False):
-            vl = self._text_varlen(text) if text.dim() == 2 else None
+            vl = self._text_varlen(text, text_lengths) if text.dim() == 2 else None
             image_features = self.encode_image(image, normalize=True)
             partner = self._gather_partner() if self._gather_partner is not None else None
             if partner is not None and self.training and torch.is_grad_enabled():

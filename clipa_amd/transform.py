@@ -212,19 +212,17 @@ def image_transform(
         interpolation: str = 'bicubic',
         square_resize_only: bool = False,
 ):
-    """Same signature, branches and ordering as open_clip/transform.py:91-214."""
-    mean = mean or OPENAI_DATASET_MEAN
-    if not isinstance(mean, (list, tuple)):
-        mean = (mean,) * 3
-    std = std or OPENAI_DATASET_STD
-    if not isinstance(std, (list, tuple)):
-        std = (std,) * 3
-    if isinstance(image_size, (list, tuple)) and image_size[0] == image_size[1]:
-        image_size = image_size[0]
-    if isinstance(aug_cfg, dict):
-        aug_cfg = AugmentationCfg(**aug_cfg)
-    else:
-        aug_cfg = aug_cfg or AugmentationCfg()
+    """The reference's transform factory (open_clip/transform.py:91-214): same signature, same argument defaults, same order of
+    the transforms, on Pillow alone."""
+    def _triple(v, default):
+        """None -> the OpenAI statistics; a scalar -> the same value for the three channels."""
+        v = default if not v else v
+        return tuple(v) if isinstance(v, (list, tuple)) else (v, v, v)
+
+    mean, std = _triple(mean, OPENAI_DATASET_MEAN), _triple(std, OPENAI_DATASET_STD)
+    if isinstance(image_size, (list, tuple)) and len(image_size) == 2 and image_size[0] == image_size[1]:
+        image_size = image_size[0]                      # a square size is passed on as an int
+    aug_cfg = AugmentationCfg(**aug_cfg) if isinstance(aug_cfg, dict) else (aug_cfg or AugmentationCfg())
     normalize = Normalize(mean=mean, std=std)
     tail = [pil_to_tensor] if to_float_on_device else [to_tensor, normalize]
     if is_train:

@@ -31,7 +31,7 @@ def _model(g):
     return m
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, unpad=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(2)
@@ -40,14 +40,16 @@ def _worker(rank, world, port, q):
     _swap()
     g = load_golden("cls_erf")
     m = _model(g)
+    m.unpad_text = bool(unpad)      # before the wrap: DDP(static_graph=True) records the autograd graph of its first iteration
     ddp = torch.nn.parallel.DistributedDataParallel(m, static_graph=True)
     B = g.images_u8.shape[0] // world
     img, txt = g.images_u8[rank * B:(rank + 1) * B], g.texts[rank * B:(rank + 1) * B]
+    lens = (txt.argmax(-1) + 1) if unpad else None      # from the loader's host-side token ids: no device read-back
     loss_fn = clipa_amd.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True, rank=rank, world_size=world).bind(ddp)
     losses, hits = [], []
     for _ in range(4):
         ddp.zero_grad(set_to_none=True)
-        out = ddp(img, txt)
+        out = ddp(img, txt, text_lengths=lens)
         loss = loss_fn(**out, output_dict=True)["contrastive_loss"]
         loss.backward()
         losses.append(float(loss.detach()))
@@ -61,11 +63,17 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_ddp_step_equals_global_batch_step():
+import pytest
+
+
+@pytest.mark.parametrize("unpad", [False, True])
+def test_two_rank_ddp_step_equals_global_batch_step(unpad):
+    """unpad: every rank runs its text tower on the tokens up to EOT (`unpad_text`, set before the DDP wrap; ragged packed
+    matrices that differ between the ranks) - the step still equals the padded single-process global-batch step."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, 29757, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, 29757 + int(unpad), q, unpad)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}

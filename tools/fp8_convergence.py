@@ -1,9 +1,11 @@
 #!/usr/bin/env python
-"""Convergence A/B of the fp8 path: the SAME model, data, seed and optimizer trained for N steps with
-precision bf16 and fp8 (e4m3 operands, e4m3 or e5m2 gradient operands) on the HIP engine, and - for the first steps - the
-fp32 CPU oracle (oracle/clip_oracle.py), on LEARNABLE synthetic pairs.
+"""Convergence A/B of the reduced-precision paths: the SAME model, data, seed and optimizer trained for N steps with
+precision bf16 (all-recompute = bit-exact gradients), bf16 with the e4m3 pre-activation kept in every block (`bf16_h8`: the
+activation plan of bench.py's `value`; VERDICT r4 next #1b) and fp8 (e4m3 operands, e4m3 or e5m2 gradient operands; VERDICT r2
+item 6a) on the HIP engine, and - for the first steps - the fp32 CPU oracle (oracle/clip_oracle.py), on LEARNABLE synthetic pairs.
 
     python tools/fp8_convergence.py --steps 200 --batch 256 > profiles/r03_fp8_convergence_S16_112.jsonl
+    python tools/fp8_convergence.py --arms bf16,bf16_h8 --lr 3e-4 --seed 1 > profiles/r05_h8_convergence_S16_112_lr3e-4_seed1.jsonl
 
 Data: C "concepts"; a pair of concept c is (image = a fixed random low-frequency pattern of c + per-sample noise, caption = a
 fixed token sequence of c with a few random filler tokens).  With C >= batch the contrastive task is learnable to a loss well
@@ -52,8 +54,14 @@ def run_engine(precision, grad_fmt, args, base, toks, length, cfg):
     dev = torch.device("cuda", 0)
     torch.manual_seed(args.seed)
     m = clipa_amd.CLIP(**cfg, output_dict=True).to(dev)
+    h8 = precision == "bf16_h8"
+    if h8:
+        precision = "bf16"
     if precision in ("bf16", "fp8"):
         clipa_amd.convert_weights_to_lp(m, torch.bfloat16)
+    if h8:    # bench.py's plan at the headline shape: every block keeps the e4m3 pre-activation, x1 and the attention output
+        for t in (m.visual.transformer, m.transformer):
+            t.keep_counts = dict(t.keep_counts, h8=t.layers, a=t.layers, x1=t.layers)
     if precision == "fp8":
         for t in (m.visual.transformer, m.transformer):
             t.fp8, t.fp8_grad_format = True, grad_fmt
@@ -119,6 +127,7 @@ def main():
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--oracle-steps", type=int, default=12)
+    ap.add_argument("--arms", default="bf16,fp8_e4m3_grad,fp8_e5m2_grad", help="comma-separated: bf16, bf16_h8, fp8_e4m3_grad, fp8_e5m2_grad")
     args = ap.parse_args()
     import clipa_amd
     cfg = clipa_amd.get_model_config("ViT-S-16")
@@ -126,7 +135,9 @@ def main():
     cfg["text_cfg"]["context_length"] = 32
     base, toks, length = make_data(args.concepts, 112, 32, cfg["text_cfg"]["vocab_size"], 42)
     runs = {}
-    for name, prec, fmt in (("bf16", "bf16", None), ("fp8_e4m3_grad", "fp8", "e4m3"), ("fp8_e5m2_grad", "fp8", "e5m2")):
+    ARMS = {"bf16": ("bf16", None), "bf16_h8": ("bf16_h8", None), "fp8_e4m3_grad": ("fp8", "e4m3"), "fp8_e5m2_grad": ("fp8", "e5m2")}
+    for name in args.arms.split(","):
+        prec, fmt = ARMS[name]
         runs[name] = run_engine(prec, fmt, args, base, toks, length, cfg)
         print(json.dumps({"run": name, "losses": [round(x, 4) for x in runs[name]]}), flush=True)
     if args.oracle_steps > 0:
@@ -134,11 +145,11 @@ def main():
         runs["oracle_fp32_cpu"] = run_oracle(args, base, toks, length, cfg, args.oracle_steps)
         print(json.dumps({"run": "oracle_fp32_cpu", "losses": [round(x, 4) for x in runs["oracle_fp32_cpu"]]}), flush=True)
     tail = lambda xs: float(np.mean(xs[-20:]))
-    summ = {"summary": True, "model": "ViT-S-16@112 + text-32", "batch": args.batch, "steps": args.steps, "ln_batch": round(math.log(args.batch), 4),
+    summ = {"summary": True, "model": "ViT-S-16@112 + text-32", "batch": args.batch, "steps": args.steps, "lr": args.lr, "seed": args.seed, "ln_batch": round(math.log(args.batch), 4),
             "final20_mean": {k: round(tail(v), 4) for k, v in runs.items() if len(v) >= 20},
             "max_abs_gap_vs_bf16": {k: round(max(abs(a - b) for a, b in zip(v, runs["bf16"])), 4) for k, v in runs.items() if k != "bf16"},
             "mean_gap_last50_vs_bf16": {k: round(float(np.mean([a - b for a, b in zip(v[-50:], runs["bf16"][-50:])])), 4)
-                                        for k, v in runs.items() if k.startswith("fp8")}}
+                                        for k, v in runs.items() if k != "bf16" and len(v) >= 50}}
     print(json.dumps(summ), flush=True)
 
 
