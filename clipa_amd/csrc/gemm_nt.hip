@@ -346,6 +346,7 @@ extern "C" int clipa_internal_debug_set(int gemm_nt_variant, int ablation_flags)
 }
 
 extern "C" int clipa_internal_last_gemm(void) { return g_last_gemm.load(std::memory_order_relaxed); }
+extern "C" int clipa_internal_debug_flags(void) { return g_abl.load(std::memory_order_relaxed); }
 
 extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, const float* bias,
                              const void* aux, int64_t M, int64_t N, int64_t K, int64_t lda,
