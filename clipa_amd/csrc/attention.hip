@@ -723,7 +723,13 @@ extern "C" int clipa_attn_wide_launch(const void* args, int64_t dh, int bwd, voi
 }
 #else
 extern "C" int clipa_attn_wide_launch(const void* args, int64_t dh, int bwd, void* stream);   // attention_wide.hip
-extern "C" int clipa_attn_bwd1_try(const void* args, int64_t dh, void* stream, int* rc);        // attention_bwd1.hip
+#ifdef CLIPA_ATTN_PERSISTENT_EXPERIMENT
+// tools/probes/attention_persistent/: the single-sweep backward / persistent forward of round 5, measured slower than the
+// kernels of this file (profiles/r05_attention_persistent_single_sweep.md); a probe build links them in and selects them with
+// clipa_internal_debug_set flags 262144 (backward) / 524288 (forward)
+extern "C" int clipa_attn_bwd1_try(const void* args, int64_t dh, void* stream, int* rc);
+extern "C" int clipa_attn_fwd1_try(const void* args, int64_t dh, void* stream, int* rc);
+#endif
 
 #define ATTN_DISPATCH(fn, dh, a, st)                 \
   if ((dh) == 80) { ATTN_DISPATCH_DH(fn, 80, a, st) } \
@@ -740,6 +746,10 @@ extern "C" int clipa_attention_fwd(const void* q, const void* k, const void* v, 
   a.stats = stats;
   if (wide_head(dh)) return clipa_attn_wide_launch(&a, dh, 0, stream);
   if (L > 288) return dispatch_long<false>(a, dh, (hipStream_t)stream);
+#ifdef CLIPA_ATTN_PERSISTENT_EXPERIMENT
+  int rc1 = 0;
+  if ((clipa_internal_debug_flags() & 524288) && clipa_attn_fwd1_try(&a, dh, stream, &rc1)) return rc1;
+#endif
   ATTN_DISPATCH(launch_fwd, dh, a, (hipStream_t)stream)
 }
 
@@ -759,9 +769,10 @@ extern "C" int clipa_attention_bwd(const void* q, const void* k, const void* v, 
   a.stats = const_cast<float*>(stats);
   if (wide_head(dh)) return clipa_attn_wide_launch(&a, dh, 1, stream);
   if (L > 288) return dispatch_long<true>(a, dh, (hipStream_t)stream);
-  // image towers at 129..224 tokens, head dim 64: the single-sweep persistent kernel (attention_bwd1.hip)
+#ifdef CLIPA_ATTN_PERSISTENT_EXPERIMENT
   int rc1 = 0;
-  if (!(clipa_internal_debug_flags() & 262144) && clipa_attn_bwd1_try(&a, dh, stream, &rc1)) return rc1;
+  if ((clipa_internal_debug_flags() & 262144) && clipa_attn_bwd1_try(&a, dh, stream, &rc1)) return rc1;
+#endif
   ATTN_DISPATCH(launch_bwd, dh, a, (hipStream_t)stream)
 }
 // ---- packed variable-length sequences -------------------------------------------------------------------------------------

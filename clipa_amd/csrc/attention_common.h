@@ -17,6 +17,7 @@ struct AttnArgs {
   // packed variable-length sequences (short kernels only; clipa_attention_*_varlen): sequence i of this launch is
   // seq_ids[i] (or i), its rows are [seq_start[s], seq_start[s] + seq_len[s]) of the token matrix, B = sequences of the launch
   const int* seq_start; const int* seq_len; const int* seq_ids;
+  int abl;        // timing ablations of the persistent kernels (internal_hooks.h; wrong results): 1 = no pair arithmetic, 2 = no output stores
 };
 
 // Geometry per head dim.  dh = 64 (ViT-S/B/L, every text tower): 128-byte LDS rows, 4 k-steps, 2 output tiles.

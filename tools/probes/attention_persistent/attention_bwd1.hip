@@ -39,19 +39,12 @@ constexpr int B1_WAVES = 8;
 // chunks) each touch every bank once.
 __device__ __forceinline__ int tswz(int key) { return (key >> 1) & 7; }
 
-template <int CUR, int NKT>
-struct B1Lds {
-  static constexpr int LP = NKT * 32, IMG = LP * 128;
-};
-
 template <int NKT>
 __global__ __launch_bounds__(64 * B1_WAVES, 1) void attn_bwd1_kernel(AttnArgs p) {
   constexpr int LP = NKT * 32, RB = 128, KS = 4, DT = 2, DH = 64, IMG = LP * RB;
-  // distinct objects on purpose (see the header): an LDS-DMA into one of them never holds up reads of another
   __shared__ __attribute__((aligned(1024))) char sQ[IMG];
   __shared__ __attribute__((aligned(1024))) char sDO[IMG];
-  __shared__ __attribute__((aligned(1024))) char sK0[IMG];
-  __shared__ __attribute__((aligned(1024))) char sK1[IMG];
+  __shared__ __attribute__((aligned(1024))) char sK[IMG];
   __shared__ __attribute__((aligned(1024))) char sRing[B1_WAVES * 4096];      // per wave: two 2 KB dS slots = one 4 KB store window
   __shared__ __attribute__((aligned(16))) float sMp[LP];
   __shared__ __attribute__((aligned(16))) float sD[LP];
@@ -66,51 +59,49 @@ __global__ __launch_bounds__(64 * B1_WAVES, 1) void attn_bwd1_kernel(AttnArgs p)
   const unsigned nrec_o = (unsigned)((long)(p.L - 1) * p.ld_o * 2 + DH * 2);
   const int tile0 = 32 * min(wave, NKT - 1);            // this wave's key tile = its query tile for dQ (spare waves: any valid tile)
   char* const myring = sRing + wave * 4096;
-  const bool keyvalid = tile0 + l31 < p.L;
+  const float sbias = (tile0 + l31 < p.L) ? 0.f : -1e30f;   // padded keys (zero K rows) must not reach dQ through dS: P = exp2(-huge) = 0
 
-  bf16x8 fv[KS], fo[KS];       // V rows of the wave's key tile (B operand of dP) / O rows of its query tile (for D), next head's
-  float2 st;                   // forward statistics of the wave's query rows, next head's
+  bf16x8 fv[KS], fo[KS];       // V rows of the wave's key tile (B operand of dP) / O rows of its query tile (for D)
+  float2 st;                   // forward statistics of the wave's query rows
 
-  // operands of head `hd` that travel through registers: issued early, consumed in that head's prologue
-  auto prefetch_regs = [&](long hd) {
+  auto head_off = [&](long hd, long ld) {
     const int b = (int)(hd / p.H), h = (int)(hd - (long)b * p.H);
-    const long row0 = (long)b * p.L;
-    const __amdgpu_buffer_rsrc_t rsV = make_rsrc(p.v + ((size_t)row0 * p.ld_qkv + (size_t)h * DH) * 2, nrec);
-    const __amdgpu_buffer_rsrc_t rsO = make_rsrc(p.o_in + ((size_t)row0 * p.ld_o + (size_t)h * DH) * 2, nrec_o);
-    load_frags<KS, DH>(rsV, p.ld_qkv, tile0 + l31, hi, fv);
-    load_frags<KS, DH>(rsO, p.ld_o, tile0 + l31, hi, fo);
+    return ((size_t)b * p.L * ld + (size_t)h * DH) * 2;
+  };
+  // operands of head `hd` that travel through registers
+  auto prefetch_regs = [&](long hd) {
+    load_frags<KS, DH>(make_rsrc(p.v + head_off(hd, p.ld_qkv), nrec), p.ld_qkv, tile0 + l31, hi, fv);
+    load_frags<KS, DH>(make_rsrc(p.o_in + head_off(hd, p.ld_o), nrec_o), p.ld_o, tile0 + l31, hi, fo);
     st = make_float2(0.f, 0.f);
     if (tile0 + l31 < p.L) st = *(const float2*)(p.stats + ((size_t)hd * p.L + tile0 + l31) * 2);
   };
   auto dma_q_do = [&](long hd) {
-    const int b = (int)(hd / p.H), h = (int)(hd - (long)b * p.H);
-    const long row0 = (long)b * p.L;
-    dma_image<DH>(make_rsrc(p.q + ((size_t)row0 * p.ld_qkv + (size_t)h * DH) * 2, nrec), sQ, LP, p.ld_qkv, wave, lane, B1_WAVES);
-    dma_image<DH>(make_rsrc(p.d_o + ((size_t)row0 * p.ld_o + (size_t)h * DH) * 2, nrec_o), sDO, LP, p.ld_o, wave, lane, B1_WAVES);
+    dma_image<DH>(make_rsrc(p.q + head_off(hd, p.ld_qkv), nrec), sQ, LP, p.ld_qkv, wave, lane, B1_WAVES);
+    dma_image<DH>(make_rsrc(p.d_o + head_off(hd, p.ld_o), nrec_o), sDO, LP, p.ld_o, wave, lane, B1_WAVES);
   };
-  auto dma_k = [&](long hd, char* img) {
-    const int b = (int)(hd / p.H), h = (int)(hd - (long)b * p.H);
-    const long row0 = (long)b * p.L;
-    dma_image<DH>(make_rsrc(p.k + ((size_t)row0 * p.ld_qkv + (size_t)h * DH) * 2, nrec), img, LP, p.ld_qkv, wave, lane, B1_WAVES);
+  auto dma_k = [&](long hd) {
+    dma_image<DH>(make_rsrc(p.k + head_off(hd, p.ld_qkv), nrec), sK, LP, p.ld_qkv, wave, lane, B1_WAVES);
   };
 
-  // one head with its K image in sKc, the next head's going into sKn
-  auto head_body = [&](long head, char* sKc, char* sKn) {
+  long head = blockIdx.x;
+  if (head >= nheads) return;
+  dma_q_do(head);
+  dma_k(head);
+  prefetch_regs(head);
+
+  for (; head < nheads; head += gridDim.x) {
     const long next = head + gridDim.x;
     const bool has_next = next < nheads;
     const int b = (int)(head / p.H), h = (int)(head - (long)b * p.H);
     const long row0 = (long)b * p.L;
 
-    // ---- prologue: this head's images have been issued one phase ago; they must have landed for every wave ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- prologue: this head's operands were issued behind the previous head's last step; they must have landed ----
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0), as an instruction hipcc's wait-count pass sees
     __syncthreads();
-    if (has_next) dma_k(next, sKn);                      // lands under this whole head
-    bf16x8 fk[KS];
     {
       float Dq = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        fk[ks] = frag_direct<DH>(sKc, tile0, l31, hi, ks);
         const bf16x8 fdo = frag_direct<DH>(sDO, tile0, l31, hi, ks);
         float a[8], o8[8];
         unpack8(__builtin_bit_cast(u32x4, fdo), a);
@@ -130,117 +121,117 @@ __global__ __launch_bounds__(64 * B1_WAVES, 1) void attn_bwd1_kernel(AttnArgs p)
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; dq[dt][r] = 0.f; }
-    const float sbias = keyvalid ? 0.f : -1e30f;        // padded keys (zero K rows) must not reach dQ through dS: P = exp2(-huge) = 0
 
-    // one step = [pair arithmetic + dS tile into the ring] barrier [dQ product from the tile another wave left].  The loop over
-    // the steps is NOT unrolled (the fragment addresses of a step depend on it only through qt / src, and hipcc would hoist all
-    // seven steps' worth of them out of the persistent head loop: 215 spilled registers); the last step is peeled so that the
-    // next head's prefetch registers are not live around the loop.
-    auto step_pair = [&](int i) {
-    if (active) {
-      int qt = wave + i;
-      if (qt >= NKT) qt -= NKT;
-      f32x16 s, dp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = sbias; dp[r] = 0.f; }
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct<DH>(sQ, 32 * qt, l31, hi, ks), fk[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct<DH>(sDO, 32 * qt, l31, hi, ks), fv[ks], dp, 0, 0, 0);
-      }
-      float pr[16], ds[16];
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int q0 = 32 * qt + 8 * rq + 4 * hi;      // query = q0 + e
-        const float4 m4 = *(const float4*)(sMp + q0);
-        const float4 d4 = *(const float4*)(sD + q0);
-        const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
-        const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * rq + e;
-          const float pe = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mm[e]));
-          pr[r] = pe;
-          ds[r] = pe * (dp[r] - dd[e]);               // (the 1/sqrt(dh) of dS rides in the dQ / dK stores)
-        }
-      }
-      char* const slot = myring + (i & 1) * 2048;
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 pf = pack_frag(pr + 8 * s2);
-        const bf16x8 dsf = pack_frag(ds + 8 * s2);
-        const u32x4 dw = __builtin_bit_cast(u32x4, dsf);
-        // T[key = l31][query = 8 j + 4 hi + e], j = 2 s2 + jj: 8 bytes per (lane, j)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          u32x2 w2;
-          w2[0] = dw[2 * jj];
-          w2[1] = dw[2 * jj + 1];
-          *(u32x2*)(slot + l31 * 64 + (((2 * (2 * s2 + jj) + hi) ^ tswz(l31)) << 3)) = w2;
-        }
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans<DH>(sDO, 32 * qt + 16 * s2, 32 * dt, hi, q16, i16), pf, dv[dt], 0, 0, 0);
-          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans<DH>(sQ, 32 * qt + 16 * s2, 32 * dt, hi, q16, i16), dsf, dk[dt], 0, 0, 0);
-        }
-      }
-    }
-    };
-    auto step_dq = [&](int i) {
-    if (active) {
-      // the tile of (query tile = mine, key tile = src) was written by wave src at this step
-      int src = wave - i;
-      if (src < 0) src += NKT;
-      const char* const T = sRing + src * 4096 + (i & 1) * 2048;
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int r0 = 16 * s2 + 4 * hi + (i16 >> 2), r1 = r0 + 8, chunk = 4 * q16 + (i16 & 3);
-        const bf16x4 ta = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) bf16x4*)(T + r0 * 64 + ((chunk ^ tswz(r0)) << 3)));
-        const bf16x4 tb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) bf16x4*)(T + r1 * 64 + ((chunk ^ tswz(r1)) << 3)));
-        bf16x8 dst;
-        dst[0] = ta[0]; dst[1] = ta[1]; dst[2] = ta[2]; dst[3] = ta[3];
-        dst[4] = tb[0]; dst[5] = tb[1]; dst[6] = tb[2]; dst[7] = tb[3];
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans<DH>(sKc, 32 * src + 16 * s2, 32 * dt, hi, q16, i16), dst, dq[dt], 0, 0, 0);
-      }
-    }
-    };
+    // One step = [pair arithmetic + dS tile into the ring] barrier [dQ product from the tile another wave left].  hipcc left to
+    // itself issues every LDS read right in front of the MFMA that consumes it (read, wait for the LDS round trip, MFMA: twenty
+    // times per step); the fragments of a group of MFMAs are therefore read as a block, fenced from the scheduler, so that the
+    // waits count down while the matrix pipe runs.  Not unrolled over the steps (the fragment addresses depend on the step only
+    // through qt / src; unrolled, hipcc hoists seven steps' worth of them out of the head loop and spills).
 #pragma unroll 1
-    for (int i = 0; i < NKT - 1; ++i) {
-      step_pair(i);
-      __syncthreads();          // every wave's dS tile of this step is in its slot
-      step_dq(i);
+    for (int i = 0; i < NKT; ++i) {
+      if (active && !(p.abl & 1)) {
+        int qt = wave + i;
+        if (qt >= NKT) qt -= NKT;
+        bf16x8 aq[KS], ad[KS], fk[KS];   // (the wave's K rows come back from the image every step: 16 registers less for the head)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          aq[ks] = frag_direct<DH>(sQ, 32 * qt, l31, hi, ks);
+          fk[ks] = frag_direct<DH>(sK, tile0, l31, hi, ks);
+          ad[ks] = frag_direct<DH>(sDO, 32 * qt, l31, hi, ks);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = sbias; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks], fk[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[ks], fv[ks], dp, 0, 0, 0);
+        }
+        // the transposed fragments of the dV / dK products land under the score MFMAs and the softmax-gradient arithmetic
+        bf16x8 tq[2][DT], td[2][DT];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            td[s2][dt] = frag_trans<DH>(sDO, 32 * qt + 16 * s2, 32 * dt, hi, q16, i16);
+            tq[s2][dt] = frag_trans<DH>(sQ, 32 * qt + 16 * s2, 32 * dt, hi, q16, i16);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        float pr[16], ds[16];
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const float4 m4 = *(const float4*)(sMp + 32 * qt + 8 * rq + 4 * hi);      // query = 32 qt + 8 rq + 4 hi + e
+          const float4 d4 = *(const float4*)(sD + 32 * qt + 8 * rq + 4 * hi);
+          const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
+          const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * rq + e;
+            const float pe = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mm[e]));
+            pr[r] = pe;
+            ds[r] = pe * (dp[r] - dd[e]);               // (the 1/sqrt(dh) of dS rides in the dQ / dK stores)
+          }
+        }
+        char* const slot = myring + (i & 1) * 2048;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pf = pack_frag(pr + 8 * s2);
+          const bf16x8 dsf = pack_frag(ds + 8 * s2);
+          const u32x4 dw = __builtin_bit_cast(u32x4, dsf);
+          // T[key = l31][query = 8 j + 4 hi + e], j = 2 s2 + jj: 8 bytes per (lane, j)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            u32x2 w2;
+            w2[0] = dw[2 * jj];
+            w2[1] = dw[2 * jj + 1];
+            *(u32x2*)(slot + l31 * 64 + (((2 * (2 * s2 + jj) + hi) ^ tswz(l31)) << 3)) = w2;
+          }
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(td[s2][dt], pf, dv[dt], 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[s2][dt], dsf, dk[dt], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();          // every wave's dS tile of this step is in its slot; (last step: the Q / dO images are free)
+      if (i == NKT - 1 && has_next) dma_q_do(next);      // the next head's images go in under the last dQ product and the stores
+      if (active && !(p.abl & 1)) {
+        // the tile of (query tile = mine, key tile = src) was written by wave src at this step
+        int src = wave - i;
+        if (src < 0) src += NKT;
+        const char* const T = sRing + src * 4096 + (i & 1) * 2048;
+        bf16x8 dst[2], kt[2][DT];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int r0 = 16 * s2 + 4 * hi + (i16 >> 2), r1 = r0 + 8, chunk = 4 * q16 + (i16 & 3);
+          const bf16x4 ta = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) bf16x4*)(T + r0 * 64 + ((chunk ^ tswz(r0)) << 3)));
+          const bf16x4 tb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) bf16x4*)(T + r1 * 64 + ((chunk ^ tswz(r1)) << 3)));
+          dst[s2][0] = ta[0]; dst[s2][1] = ta[1]; dst[s2][2] = ta[2]; dst[s2][3] = ta[3];
+          dst[s2][4] = tb[0]; dst[s2][5] = tb[1]; dst[s2][6] = tb[2]; dst[s2][7] = tb[3];
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) kt[s2][dt] = frag_trans<DH>(sK, 32 * src + 16 * s2, 32 * dt, hi, q16, i16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+            dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt[s2][dt], dst[s2], dq[dt], 0, 0, 0);
+      }
     }
-    step_pair(NKT - 1);
-    __syncthreads();            // ... and the Q / dO images are free: the next head's go in under the last dQ product and the stores
+    __syncthreads();            // every ring slot has been read: the ring becomes the waves' store windows; the K image is free
     if (has_next) {
-      dma_q_do(next);
-      prefetch_regs(next);
+      dma_k(next);
+      prefetch_regs(next);      // V / O rows and statistics of the next head: land under the stores
     }
-    step_dq(NKT - 1);
-    __syncthreads();            // every ring slot has been read: the ring becomes the waves' store windows; sKc is free
-    if (active) {
+    if (active && !(p.abl & 2)) {
       store_tile64(myring, p.dk, p.ld_dqkv, row0 + tile0, p.L - tile0, h * DH, lane, dk[0], dk[1], p.scale);
       store_tile64(myring, p.dv, p.ld_dqkv, row0 + tile0, p.L - tile0, h * DH, lane, dv[0], dv[1], 1.0f);
       store_tile64(myring, p.dq, p.ld_dqkv, row0 + tile0, p.L - tile0, h * DH, lane, dq[0], dq[1], p.scale);
     }
-  };
-
-  long head = blockIdx.x;
-  if (head >= nheads) return;
-  dma_q_do(head);
-  dma_k(head, sK0);
-  prefetch_regs(head);
-  for (;;) {
-    head_body(head, sK0, sK1);
-    head += gridDim.x;
-    if (head >= nheads) break;
-    head_body(head, sK1, sK0);
-    head += gridDim.x;
-    if (head >= nheads) break;
   }
 }
 
@@ -267,8 +258,10 @@ int launch_bwd1(const AttnArgs& a, hipStream_t st) {
 }  // namespace
 
 // -> 1 if the single-sweep kernel covers this problem (and was launched: *rc = its return code), 0 if the caller keeps its own
+extern "C" int clipa_internal_debug_flags(void);
 extern "C" int clipa_attn_bwd1_try(const void* args, int64_t dh, void* stream, int* rc) {
-  const AttnArgs& a = *(const AttnArgs*)args;
+  AttnArgs a = *(const AttnArgs*)args;
+  a.abl = (clipa_internal_debug_flags() >> 20) & 3;      // (bits 20 / 21 of the experiment flags)
   const int nkt = (a.L + 31) / 32;
   if (dh != 64 || a.causal || a.seq_len || nkt < 5 || nkt > 7) return 0;
   switch (nkt) {

@@ -14,6 +14,7 @@ typedef int (*fwd_t)(const void*, const void*, const void*, void*, float*, int64
 typedef int (*bwd_t)(const void*, const void*, const void*, const void*, const void*, const float*, void*, void*, void*, int64_t, int64_t, int64_t,
                      int64_t, int64_t, int64_t, int64_t, float, int, void*);
 typedef const char* (*err_t)(void);
+typedef int (*dbg_t)(int, int);
 __global__ void fill_bf16(unsigned short* p, size_t n, unsigned seed, float scale) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     unsigned h = (unsigned)i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
@@ -43,11 +44,11 @@ __global__ void nan_words(const unsigned short* a, size_t n, unsigned long long*
 int main(int argc, char** argv) {
   const int NL = argc - 1;
   if (NL < 1) { printf("usage: attn_ab libA.so [libB.so ...]\n"); return 1; }
-  std::vector<fwd_t> F(NL); std::vector<bwd_t> Bw(NL); std::vector<err_t> E(NL);
+  std::vector<fwd_t> F(NL); std::vector<bwd_t> Bw(NL); std::vector<err_t> E(NL); std::vector<dbg_t> Dbg(NL);
   for (int i = 0; i < NL; ++i) {
     void* h = dlopen(argv[i + 1], RTLD_NOW | RTLD_LOCAL);
     if (!h) { printf("dlopen %s: %s\n", argv[i + 1], dlerror()); return 1; }
-    F[i] = (fwd_t)dlsym(h, "clipa_attention_fwd"); Bw[i] = (bwd_t)dlsym(h, "clipa_attention_bwd"); E[i] = (err_t)dlsym(h, "clipa_last_error");
+    F[i] = (fwd_t)dlsym(h, "clipa_attention_fwd"); Bw[i] = (bwd_t)dlsym(h, "clipa_attention_bwd"); E[i] = (err_t)dlsym(h, "clipa_last_error"); Dbg[i] = (dbg_t)dlsym(h, "clipa_internal_debug_set");
   }
   hipStream_t st; CK(hipStreamCreate(&st));
   unsigned long long* cnt; CK(hipMalloc(&cnt, 8));
@@ -55,7 +56,10 @@ int main(int argc, char** argv) {
   const Shape shapes[] = {{4096, 16, 197, 64, 0}, {4096, 12, 197, 64, 0}, {4096, 12, 77, 64, 1}, {2048, 16, 257, 80, 0},
                           {2048, 16, 145, 64, 0}, {4096, 16, 50, 64, 0}, {4096, 8, 32, 64, 1}, {1024, 16, 256, 64, 1}, {512, 16, 200, 64, 0},
                           {1024, 16, 50, 80, 0}, {512, 16, 77, 80, 1}, {256, 16, 100, 80, 0}, {256, 16, 26, 80, 0}, {128, 16, 288, 80, 0}};
+  const int nshapes = getenv("ATTN_AB_NSHAPES") ? atoi(getenv("ATTN_AB_NSHAPES")) : 1000;
+  int shape_no = 0;
   for (const Shape& s : shapes) {
+    if (shape_no++ >= nshapes) break;
     const long D = s.H * s.dh, T = s.B * s.L;
     unsigned short *qkv, *dO; CK(hipMalloc(&qkv, (size_t)T * 3 * D * 2)); CK(hipMalloc(&dO, (size_t)T * D * 2));
     fill_bf16<<<4096, 256, 0, st>>>(qkv, (size_t)T * 3 * D, 1u, 1.0f); fill_bf16<<<4096, 256, 0, st>>>(dO, (size_t)T * D, 2u, 1.0f);
@@ -98,6 +102,27 @@ int main(int argc, char** argv) {
       printf(", \"%s_ms\": [", which ? "bwd" : "fwd");
       for (int i = 0; i < NL; ++i) { std::sort(ts[i].begin(), ts[i].end()); printf("%s%.4f", i ? ", " : "", ts[i][2]); }
       printf("]");
+    }
+    // ATTN_AB_ABL="f1,f2,..." (with CLIPA_DEBUG_HOOKS=1): the LAST library's backward timed under each experiment-flag word
+    // (clipa_internal_debug_set(0, f): timing ablations, wrong results) - medians of 5 x 3 launches
+    if (const char* abl = getenv("ATTN_AB_ABL")) {
+      printf(", \"bwd_ablation_ms\": {");
+      const char* q = abl; bool first = true;
+      while (*q) {
+        const int f = (int)strtol(q, (char**)&q, 10); if (*q == ',') ++q;
+        if (Dbg[NL - 1](0, f)) { printf("\"%d\": \"refused: %s\"", f, E[NL - 1]()); break; }
+        std::vector<float> ts;
+        for (int r = 0; r < 5; ++r) {
+          CK(hipEventRecord(e0, st));
+          for (int k = 0; k < 3; ++k) bwd(NL - 1);
+          CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+          float x; CK(hipEventElapsedTime(&x, e0, e1)); ts.push_back(x / 3);
+        }
+        std::sort(ts.begin(), ts.end());
+        printf("%s\"%d\": %.4f", first ? "" : ", ", f, ts[2]); first = false;
+      }
+      Dbg[NL - 1](0, 0);
+      printf("}");
     }
     printf("}\n"); fflush(stdout);
     CK(hipFree(qkv)); CK(hipFree(dO));
