@@ -537,7 +537,8 @@ def main():
             final_budget -= 12 << 30
             keep_v, keep_t, med_v, med_t = plan(final_budget)
             set_keep(int(keep_v), int(keep_t), int(med_v), int(med_t))
-    gather_wait_ms = loss_mod.wait_timing_stop() / args.steps if dist_on else 0.0
+    retries_timed = int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0))     # through the timed region (the extra regions
+    gather_wait_ms = loss_mod.wait_timing_stop() / args.steps if dist_on else 0.0      # below re-shape the allocator's segments)
     last_loss = float(loss)
     if dist_on:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -719,7 +720,8 @@ def main():
             "mfu_peak_tflops": mfu_peak, "executed_gflop_per_pair": round(gf - gf_pruned, 2),
             "alloc_conf": args.alloc_conf, "loss": round(last_loss, 4), "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
             "peak_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2**30, 1),
-            "alloc_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)),
+            "alloc_retries": retries_timed,
+            "alloc_retries_incl_extra_regions": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)),
             "keep_plan_backoffs": backoffs,
             "keep_plan_second_pass_gb": None if second_pass is None else round(second_pass / 2**30, 1),
             "total_hbm_gb": round(total_mem / 2**30, 1),

@@ -300,7 +300,7 @@ def test_fp8_full_dims_match_reference_golden(golden_full):
     gradient cosine min 0.902..0.926 - always a LayerNorm gain or bias of the text tower - median 0.947..0.954, norm ratio
     0.81..1.15), with a margin; what that accuracy means for training is the convergence A/B of
     profiles/r03_fp8_convergence_S16_112.jsonl."""
-    _check_fp8_model(golden_full, 4e-2, 0.02, 0.88, 0.94, 0.22)
+    _check_fp8_model(golden_full, 4e-2, 0.02, 0.89, 0.94, 0.22)
 
 
 def test_fp8_recompute_equals_stored_activations():
