@@ -104,7 +104,7 @@ def plan_keep(budget, layers_v, layers_t, mv_b, mt_b, lv_b, lt_b):
     return int(kv), int(kt), int(mv - kv), int(mt - kt)
 
 
-# What one GB of a kept tensor saves in the backward (ms per GB at ViT-L/16 + text-77, local batch 4096): the e4m3
+# What one GB of a kept tensor saves in the backward (ms per GB at ViT-L/16 + text-77, local batch 4096; profiles/NOTEBOOK.md 7d): the e4m3
 # pre-activation replaces the c_fc recompute GEMM by an HBM-bound re-materialisation, the attention output / x1 / qkv each save the
 # kernel that would recompute them (LN1 is needed for the weight gradient either way).  Only the ORDER matters to the planner.
 KEEP_VALUE_MS_PER_GB = (("v", "h8", 1.5), ("t", "h8", 1.13), ("v", "a", 0.94), ("v", "x1", 0.91), ("t", "x1", 0.88),
@@ -594,7 +594,7 @@ def main():
         torch.cuda.empty_cache()
         set_keep(0, 0)
 
-    # The engine's unpad_text knob: same inputs, same features / loss / gradients, the causal text tower on the
+    # The engine's unpad_text knob (profiles/NOTEBOOK.md 7d): same inputs, same features / loss / gradients, the causal text tower on the
     # tokens up to each caption's EOT (SURVEY 8d's caption lengths ~ N(20, 8): about a quarter of the 77 positions).  Never
     # part of `value`, which stays on the reference's schedule unless --unpad-text asks otherwise.
     unpad = None
