@@ -175,8 +175,13 @@ __global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void att
       load_frags<KS, DH>(rsDO, p.ld_o, qg, hi, fdo);
       load_frags<KS, DH>(rsO, p.ld_o, qg, hi, fo);
     }
-    float2 st = make_float2(0.f, 0.f);                 // padded queries: inv = 0 -> P = 0
-    if (qg < p.L) st = *(const float2*)(stats + qg * 2);
+    // P = exp2(c s - c rowmax) / rowsum = exp2(c s - m'), m' = c rowmax + log2(rowsum): the forward's two statistics fold into
+    // one exponent offset per query (one multiply per score less in both sweeps); padded queries: m' = +huge -> P = 0
+    float mp = 1e30f;
+    if (qg < p.L) {
+      const float2 st = *(const float2*)(stats + qg * 2);
+      mp = st.x - __builtin_amdgcn_logf(st.y);
+    }
     float Dq = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -187,7 +192,7 @@ __global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void att
       for (int i = 0; i < 8; ++i) Dq += a[i] * o8[i];
     }
     Dq += __shfl_xor(Dq, 32, 64);
-    if (hi == 0) { sM[qg] = st.x; sL[qg] = st.y; sD[qg] = Dq; }
+    if (hi == 0) { sM[qg] = mp; sD[qg] = Dq; }
     const int lim2 = (CAUSAL ? min(p.L, qg + 1) : p.L) - 4 * hi;
     f32x16 dq[DT];
 #pragma unroll
@@ -210,9 +215,9 @@ __global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void att
       float ds[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float pe = __builtin_amdgcn_exp2f(fmaf(s[r], c, -st.x)) * st.y;
+        float pe = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mp));
         if (!full) pe = (32 * kt + 8 * (r >> 2) + (r & 3) < lim2) ? pe : 0.f;
-        ds[r] = pe * (dp[r] - Dq) * p.scale;
+        ds[r] = pe * (dp[r] - Dq);                     // (the 1 / sqrt(dh) of dS rides in the dQ / dK stores)
       }
       if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -224,11 +229,11 @@ __global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void att
       }
     }
     if constexpr (STAGE) {
-      if (live) store_tile<DH>(stage, p.dq, p.ld_dqkv, row0 + 32 * qt, p.L - 32 * qt, h * DH, lane, dq, 1.0f);
+      if (live) store_tile<DH>(stage, p.dq, p.ld_dqkv, row0 + 32 * qt, p.L - 32 * qt, h * DH, lane, dq, p.scale);
     } else if (qg < p.L && live) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
-        store_frag_T(p.dq, p.ld_dqkv, row0 + qg, h * DH + 32 * dt, hi, dq[dt], 1.0f, DH - 32 * dt);
+        store_frag_T(p.dq, p.ld_dqkv, row0 + qg, h * DH + 32 * dt, hi, dq[dt], p.scale, DH - 32 * dt);
     }
   }
   // the wave's first key tile of phase 2 is still in the K / V images: same register layout as the row-wise global load, which
@@ -275,20 +280,18 @@ __global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void att
       for (int rq = 0; rq < 4; ++rq) {
         const int q0 = 32 * qt + 8 * rq + 4 * hi;
         const float4 m4 = *(const float4*)(sM + q0);
-        const float4 l4 = *(const float4*)(sL + q0);
         const float4 d4 = *(const float4*)(sD + q0);
         const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
-        const float ll[4] = {l4.x, l4.y, l4.z, l4.w};
         const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * rq + e;
-          // query = 32qt + 8rq + e + 4hi.  Padded queries carry inv = 0; padded keys need no mask: their
+          // query = 32qt + 8rq + e + 4hi.  Padded queries carry m' = +huge (P = 0); padded keys need no mask: their
           // K/V rows are zero, their column is never stored and never mixes into other lanes' columns.
-          float pe = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mm[e])) * ll[e];
+          float pe = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mm[e]));
           if (CAUSAL && qt == kt) pe = (kgc <= 8 * rq + e) ? pe : 0.f;
           pr[r] = pe;
-          ds[r] = pe * (dp[r] - dd[e]) * p.scale;
+          ds[r] = pe * (dp[r] - dd[e]);
         }
       }
       if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
@@ -305,13 +308,13 @@ __global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void att
     }
     if constexpr (STAGE) {
       if (live) {
-        store_tile<DH>(stage, p.dk, p.ld_dqkv, row0 + 32 * kt, p.L - 32 * kt, h * DH, lane, dk, 1.0f);
+        store_tile<DH>(stage, p.dk, p.ld_dqkv, row0 + 32 * kt, p.L - 32 * kt, h * DH, lane, dk, p.scale);
         store_tile<DH>(stage, p.dv, p.ld_dqkv, row0 + 32 * kt, p.L - 32 * kt, h * DH, lane, dv, 1.0f);
       }
     } else if (kg < p.L && live) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        store_frag_T(p.dk, p.ld_dqkv, row0 + kg, h * DH + 32 * dt, hi, dk[dt], 1.0f, DH - 32 * dt);
+        store_frag_T(p.dk, p.ld_dqkv, row0 + kg, h * DH + 32 * dt, hi, dk[dt], p.scale, DH - 32 * dt);
         store_frag_T(p.dv, p.ld_dqkv, row0 + kg, h * DH + 32 * dt, hi, dv[dt], 1.0f, DH - 32 * dt);
       }
     }

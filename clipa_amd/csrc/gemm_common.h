@@ -29,10 +29,15 @@ struct NTArgs {
 // Tile order of the persistent NT kernels: an XCD walks groups of `gm` A panels, N-tile major inside a group.  More panels per
 // group = fewer passes of the weight matrix through the fabric (it does not fit one XCD's 4 MiB L2 and is re-fetched once per
 // group); the group's A panels must stay cache-resident while the N tiles go by.  Measured (r02_gemm_tile_group_size_ab.jsonl):
-// 8 for wide outputs, 16 for narrow ones, capped at 8 MiB of A panels per group.
+// 8 for wide outputs, 16 for narrow ones, capped at 8 MiB of A panels per group.  Round 5 (r05_gemm_nta_tile_group_size_sweep.jsonl,
+// M = 806 912): with four N tiles (1024-wide outputs of long-K products, the input-gradient GEMMs of the in-projection and of
+// c_fc) a group of EIGHT panels is exactly the 32 tiles an XCD runs side by side - 1285 -> 1347 TF/s at K = 3072 where the cap
+// gave 5 panels (a group and a half per XCD round), 1390 -> 1401 at K = 4096 (cap: 4) - so that case takes 8 up to 16 MiB.
 inline int nt_group_size(long tilesN, long panel_bytes) {
+  const long pb = panel_bytes > 0 ? panel_bytes : 1;
+  if (tilesN == 4 && 8 * pb <= (16L << 20)) return 8;
   const long want = tilesN <= 12 ? 16 : 8;
-  const long cap = (8L << 20) / (panel_bytes > 0 ? panel_bytes : 1);
+  const long cap = (8L << 20) / pb;
   const long g = want < cap ? want : cap;
   return (int)(g < 2 ? 2 : g);
 }

@@ -48,6 +48,10 @@ for s in $STAGES; do
     attnab)
       # several builds of the attention kernels side by side (tools/probes/attn_ab.hip): outputs compared on the device, timed interleaved
       timeout 600 ./tools/probes/attn_ab ${ATTNAB_ARGS:-} > gpurun_out/attn_ab.jsonl 2>&1; echo "rc=$?" >> gpurun_out/attn_ab.jsonl; tail -30 gpurun_out/attn_ab.jsonl | cut -c1-400 ;;
+    flagsweep)
+      # clipa_gemm_nt at the production launch shapes under a list of experiment-flag words (tile-group size override = gm << 20)
+      timeout 600 ./tools/probes/gemm_flag_sweep ${FLAGSWEEP_ARGS:-0 2097152 4194304 8388608 16777216 33554432} > gpurun_out/gemm_flag_sweep.jsonl 2>&1; echo "rc=$?" >> gpurun_out/gemm_flag_sweep.jsonl
+      cat gpurun_out/gemm_flag_sweep.jsonl | cut -c1-400 ;;
     smoke)
       timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "rc=$?" >> gpurun_out/smoke.log; tail -2 gpurun_out/smoke.log ;;
     vendor)
