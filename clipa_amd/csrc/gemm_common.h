@@ -35,7 +35,7 @@ struct NTArgs {
 // gave 5 panels (a group and a half per XCD round), 1390 -> 1401 at K = 4096 (cap: 4) - so that case takes 8 up to 16 MiB.
 inline int nt_group_size(long tilesN, long panel_bytes) {
   const long pb = panel_bytes > 0 ? panel_bytes : 1;
-  if (tilesN == 4 && 8 * pb <= (16L << 20)) return 8;
+  if (tilesN == 4 && pb >= (1L << 20) && 8 * pb <= (16L << 20)) return 8;      // (K >= 2048; K = 1024 keeps 16: 1047-1051 vs 1040)
   const long want = tilesN <= 12 ? 16 : 8;
   const long cap = (8L << 20) / pb;
   const long g = want < cap ? want : cap;
