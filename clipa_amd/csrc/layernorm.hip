@@ -108,11 +108,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
 
 // dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)) [+ dres];  dxhat = dy * gamma
 // dgamma / dbeta: per-block partial sums -> part[2][gridDim.x][D]
-template <int NCH, bool XF32, bool YF32>
+// EMIT (round 5): additionally y = LayerNorm(x) - the forward's output, bit for bit (same statistics, same expression) - for the
+// weight-gradient GEMM of the layer that followed the LayerNorm: a block that recomputes that operand in backward gets it from
+// the pass that has the row and its statistics in registers anyway (one more 2 D-byte store per row) instead of from a second
+// ln_fwd launch over the same rows (a 2 D-byte read and a 2 D-byte write per row).
+template <int NCH, bool XF32, bool YF32, bool EMIT = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
                                                      const void* __restrict__ dy, const void* __restrict__ dres,
                                                      void* __restrict__ dx, float* __restrict__ part,
-                                                     long rows, int D, float eps, int C) {
+                                                     long rows, int D, float eps, int C,
+                                                     const float* __restrict__ beta = nullptr, void* __restrict__ yout = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -130,6 +135,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
     for (int i = 0; i < 8; ++i) { dg[c][i] = 0.f; db[c][i] = 0.f; g[c][i] = 0.f; }
     if (ch < nchunks) ld8<true, false>(gamma, (size_t)ch * 8, g[c]);
   }
+  // (EMIT: beta is re-read per row from L1 / L2 - 4 KB shared by every wave - rather than held in NCH * 8 more registers)
   const float invD = 1.0f / (float)D;
   for (long r = row_first; r < row_end; r += row_step) {
     float v[NCH][8], d[NCH][8];
@@ -155,6 +161,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
       }
     }
     const float rstd = rsqrtf(wave_sum(ss) * invD + eps);
+    if constexpr (EMIT) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunks) {
+          float bt[8], o[8];
+          ld8<true, false>(beta, (size_t)ch * 8, bt);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = (v[c][i] - mean) * rstd * g[c][i] + bt[i];      // ln_fwd_kernel's expression
+          st8<YF32>(yout, (size_t)r * D + (size_t)ch * 8, o);
+        }
+      }
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -281,8 +300,16 @@ void launch_fwd(const void* x, const float* g, const float* b, void* y, long row
 }
 template <int NCH>
 void launch_bwd(const void* x, const float* g, const void* dy, const void* dres, void* dx, float* part,
-                long rows, int D, float eps, int xf32, int yf32, int grid, int C, hipStream_t st) {
+                long rows, int D, float eps, int xf32, int yf32, int grid, int C, hipStream_t st,
+                const float* beta = nullptr, void* yout = nullptr) {
   const size_t lds = (size_t)8 * D * sizeof(float);
+  if (yout) {     // the emitting form: the engine's bf16 token matrices and the f32 rows of the heads
+    if (xf32 && yf32) hipLaunchKernelGGL((ln_bwd_kernel<NCH, true, true, true>), dim3(grid), dim3(256), lds, st, x, g, dy, dres, dx, part, rows, D, eps, C, beta, yout);
+    else if (xf32) hipLaunchKernelGGL((ln_bwd_kernel<NCH, true, false, true>), dim3(grid), dim3(256), lds, st, x, g, dy, dres, dx, part, rows, D, eps, C, beta, yout);
+    else if (yf32) hipLaunchKernelGGL((ln_bwd_kernel<NCH, false, true, true>), dim3(grid), dim3(256), lds, st, x, g, dy, dres, dx, part, rows, D, eps, C, beta, yout);
+    else hipLaunchKernelGGL((ln_bwd_kernel<NCH, false, false, true>), dim3(grid), dim3(256), lds, st, x, g, dy, dres, dx, part, rows, D, eps, C, beta, yout);
+    return;
+  }
   if (xf32 && yf32) hipLaunchKernelGGL((ln_bwd_kernel<NCH, true, true>), dim3(grid), dim3(256), lds, st, x, g, dy, dres, dx, part, rows, D, eps, C);
   else if (xf32) hipLaunchKernelGGL((ln_bwd_kernel<NCH, true, false>), dim3(grid), dim3(256), lds, st, x, g, dy, dres, dx, part, rows, D, eps, C);
   else if (yf32) hipLaunchKernelGGL((ln_bwd_kernel<NCH, false, true>), dim3(grid), dim3(256), lds, st, x, g, dy, dres, dx, part, rows, D, eps, C);
@@ -307,20 +334,41 @@ extern "C" int64_t clipa_layernorm_bwd_workspace(int64_t rows, int64_t D) {
   return (int64_t)2 * (ln_bwd_grid(rows, D) + LN_BWD_SLICES) * D * sizeof(float);   // [2][blocks][D] + [2][slices][D]
 }
 
+namespace {
+int ln_bwd_impl(const void* x, const float* gamma, const float* beta, const void* dy, const void* dres, void* dx, void* y,
+                float* dgamma, float* dbeta, int64_t rows, int64_t D, float eps, int x_f32, int y_f32, void* workspace,
+                int64_t workspace_bytes, void* stream);
+}
+
 extern "C" int clipa_layernorm_bwd(const void* x, const float* gamma, const void* dy, const void* dres,
                                    void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t D,
                                    float eps, int x_f32, int y_f32, void* workspace,
                                    int64_t workspace_bytes, void* stream) {
+  return ln_bwd_impl(x, gamma, nullptr, dy, dres, dx, nullptr, dgamma, dbeta, rows, D, eps, x_f32, y_f32, workspace, workspace_bytes, stream);
+}
+
+extern "C" int clipa_layernorm_bwd_y(const void* x, const float* gamma, const float* beta, const void* dy, const void* dres,
+                                     void* dx, void* y, float* dgamma, float* dbeta, int64_t rows, int64_t D,
+                                     float eps, int x_f32, int y_f32, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+  if (!beta || !y) { clipa_set_error("layernorm_bwd_y: beta and y are required"); return CLIPA_ERR_ARG; }
+  return ln_bwd_impl(x, gamma, beta, dy, dres, dx, y, dgamma, dbeta, rows, D, eps, x_f32, y_f32, workspace, workspace_bytes, stream);
+}
+
+namespace {
+int ln_bwd_impl(const void* x, const float* gamma, const float* beta, const void* dy, const void* dres, void* dx, void* y,
+                float* dgamma, float* dbeta, int64_t rows, int64_t D, float eps, int x_f32, int y_f32, void* workspace,
+                int64_t workspace_bytes, void* stream) {
   if (D % 8 != 0 || D <= 0 || D > 2048) { clipa_set_error("layernorm: D=%ld must be a multiple of 8 in (0, 2048]", (long)D); return CLIPA_ERR_ARG; }
   if (rows <= 0) return CLIPA_OK;
   if (!workspace || workspace_bytes < clipa_layernorm_bwd_workspace(rows, D)) { clipa_set_error("layernorm_bwd: workspace too small"); return CLIPA_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
   const int grid = (int)ln_bwd_grid(rows, D), C = ln_bwd_chunk(rows, D);
   float* part = (float*)workspace;
-  if (D <= 512) launch_bwd<1>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, C, st);
-  else if (D <= 1024) launch_bwd<2>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, C, st);
-  else if (D <= 1536) launch_bwd<3>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, C, st);
-  else launch_bwd<4>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, C, st);
+  if (D <= 512) launch_bwd<1>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, C, st, beta, y);
+  else if (D <= 1024) launch_bwd<2>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, C, st, beta, y);
+  else if (D <= 1536) launch_bwd<3>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, C, st, beta, y);
+  else launch_bwd<4>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, C, st, beta, y);
   if (int rc = clipa_check_launch("layernorm_bwd")) return rc;
   const unsigned cols = (unsigned)((D + 63) / 64);
   if (grid <= 8 * LN_BWD_SLICES) {
@@ -334,3 +382,4 @@ extern "C" int clipa_layernorm_bwd(const void* x, const float* gamma, const void
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cols), dim3(256), 0, st, part2, dgamma, dbeta, LN_BWD_SLICES, (int)D, LN_BWD_SLICES);
   return clipa_check_launch("layernorm_bwd_reduce2");
 }
+}  // namespace

@@ -197,6 +197,13 @@ def _block_backward(x, dy, box, P, cfg):
         g, hpre = ops.gemm_nt(h2, P["w_fc"], P["b_fc"], epi=ops.EPI_ACT, act=act, want_pre=True)
     elif g is None:      # "light" block: cheap HBM-bound re-materialisation instead of 4 GEMMs + attention
         g = ops.activation_fwd(hpre, act)
+    # LayerNorm outputs that only the weight gradients still need (h2 of a block that kept or re-materialised its MLP
+    # intermediates, h1 of a block that kept qkv) are written by the LayerNorm BACKWARD pass, which has every row and its
+    # statistics in registers anyway (ops.layernorm_bwd(beta=...): bit for bit ln_fwd's output) - one more store per row instead of
+    # a second ln_fwd launch over the same rows; the weight gradient of c_fc / the in-projection then follows its LayerNorm
+    # backward instead of preceding it.  The fp8 engine keeps the order of round 4 (its LayerNorms emit e4m3 operands).
+    emit2, emit1 = (h2 is None and not fp8), (h1 is None and not fp8)
+    if h2 is None and fp8:
         h2 = ops.layernorm_fwd(x1, P["ln2_w"], P["ln2_b"], cfg["eps"])
     # y = x1 + c_proj(g).  The weight gradient goes first: g ([M, 4D], the largest transient of the block) is released before
     # the GELU-backward GEMM allocates its output of the same size
@@ -208,21 +215,32 @@ def _block_backward(x, dy, box, P, cfg):
         dh = ops.gemm_nt(dy, P["wt_proj"], epi=ops.EPI_DACT, act=act, aux=hpre)     # [M,4D]
     del hpre
     dh2 = _dlin8(dh, P, "fc", cfg) if fp8 else ops.gemm_nt(dh, P["wt_fc"])       # [M,D]
-    d_w_fc, d_b_fc = ops.gemm_tn(dh, h2, P["dt_w_fc"], want_colsum=True)
-    del dh, h2
-    dx1, d_ln2_w, d_ln2_b = ops.layernorm_bwd(x1, P["ln2_w"], dh2, dres=dy, eps=cfg["eps"])
-    del dh2, x1
+    if emit2:
+        dx1, d_ln2_w, d_ln2_b, h2 = ops.layernorm_bwd(x1, P["ln2_w"], dh2, dres=dy, eps=cfg["eps"], beta=P["ln2_b"])
+        del dh2, x1
+        d_w_fc, d_b_fc = ops.gemm_tn(dh, h2, P["dt_w_fc"], want_colsum=True)
+        del dh, h2
+    else:
+        d_w_fc, d_b_fc = ops.gemm_tn(dh, h2, P["dt_w_fc"], want_colsum=True)
+        del dh, h2
+        dx1, d_ln2_w, d_ln2_b = ops.layernorm_bwd(x1, P["ln2_w"], dh2, dres=dy, eps=cfg["eps"])
+        del dh2, x1
     # x1 = x + out_proj(a)
     da = _dlin8(dx1, P, "out", cfg) if fp8 else ops.gemm_nt(dx1, P["wt_out"])
     d_w_out, d_b_out = ops.gemm_tn(dx1, a, P["dt_w_out"], want_colsum=True)
     dqkv = _attn_bwd(qkv, a, da, stats, cfg)
     del da, a, qkv, stats
     dh1 = _dlin8(dqkv, P, "in", cfg) if fp8 else ops.gemm_nt(dqkv, P["wt_in"])
-    if h1 is None:
-        h1 = ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"])
-    d_w_in, d_b_in = ops.gemm_tn(dqkv, h1, P["dt_w_in"], want_colsum=True)
-    del dqkv, h1
-    dx, d_ln1_w, d_ln1_b = ops.layernorm_bwd(x, P["ln1_w"], dh1, dres=dx1, eps=cfg["eps"])
+    if emit1:
+        dx, d_ln1_w, d_ln1_b, h1 = ops.layernorm_bwd(x, P["ln1_w"], dh1, dres=dx1, eps=cfg["eps"], beta=P["ln1_b"])
+        d_w_in, d_b_in = ops.gemm_tn(dqkv, h1, P["dt_w_in"], want_colsum=True)
+        del dqkv, h1
+    else:
+        if h1 is None:
+            h1 = ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"])
+        d_w_in, d_b_in = ops.gemm_tn(dqkv, h1, P["dt_w_in"], want_colsum=True)
+        del dqkv, h1
+        dx, d_ln1_w, d_ln1_b = ops.layernorm_bwd(x, P["ln1_w"], dh1, dres=dx1, eps=cfg["eps"])
     return dx, (d_ln1_w, d_ln1_b, d_w_in, d_b_in, d_w_out, d_b_out, d_ln2_w, d_ln2_b, d_w_fc, d_b_fc, d_w_proj,
                 d_b_proj)
 

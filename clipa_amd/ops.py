@@ -270,8 +270,9 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=None):
     return y
 
 
-def layernorm_bwd(x, gamma, dy, dres=None, eps=1e-5):
-    """Returns dx (dtype of x, + dres if given), dgamma, dbeta (f32)."""
+def layernorm_bwd(x, gamma, dy, dres=None, eps=1e-5, beta=None):
+    """Returns dx (dtype of x, + dres if given), dgamma, dbeta (f32) - and, when `beta` is given, y = LayerNorm(x) (dtype of
+    dy) as a fourth value: bit for bit what layernorm_fwd returns, written by the pass that has the rows in registers anyway."""
     x = x.contiguous()
     dy = dy.contiguous()
     D = x.shape[-1]
@@ -286,6 +287,13 @@ def layernorm_bwd(x, gamma, dy, dres=None, eps=1e-5):
         if dres.dtype != x.dtype:
             raise RuntimeError("layernorm_bwd: dres dtype must match x")
     nbytes = float(rows) * D * (2 * x.element_size() + dy.element_size() + (x.element_size() if dres is not None else 0))
+    if beta is not None:
+        _chk(beta, f32, "beta", 1)
+        y = torch.empty(x.shape, device=x.device, dtype=dy.dtype)
+        with _Timed("ln_bwd", 0.0, nbytes + float(rows) * D * y.element_size(), f"{rows},{D},+y"):
+            lib.call("clipa_layernorm_bwd_y", _p(x), _p(gamma), _p(beta), _p(dy), _p(dres), _p(dx), _p(y), _p(dgamma), _p(dbeta),
+                     rows, D, float(eps), int(x.dtype == f32), int(dy.dtype == f32), _p(ws), wsb, _stream())
+        return dx, dgamma, dbeta, y
     with _Timed("ln_bwd", 0.0, nbytes, f"{rows},{D}"):
         lib.call("clipa_layernorm_bwd", _p(x), _p(gamma), _p(dy), _p(dres), _p(dx), _p(dgamma), _p(dbeta), rows, D,
                  float(eps), int(x.dtype == f32), int(dy.dtype == f32), _p(ws), wsb, _stream())

@@ -87,13 +87,19 @@ int clipa_layernorm_fwd_q8(const void* x, const float* gamma, const float* beta,
                            int64_t rows, int64_t D, float eps, void* stream);
 
 /* F.layer_norm over the last dim, eps inside sqrt, affine (transformer.py:19-34). x/dx share a dtype
- * (x_f32), y/dy share a dtype (y_f32). bwd: dx = LN'(dy) [+ dres]; dgamma, dbeta f32 [D]. */
+ * (x_f32), y/dy share a dtype (y_f32). bwd: dx = LN'(dy) [+ dres]; dgamma, dbeta f32 [D].
+ * clipa_layernorm_bwd_y: the same backward that also writes y = LayerNorm(x) (dtype of dy), bit for bit what
+ * clipa_layernorm_fwd writes - the operand of the following layer's weight gradient when a block recomputes its LayerNorm
+ * outputs in backward (the reference's checkpointed block re-runs ln_1 / ln_2 there, transformer.py:238-250,320-325). */
 int clipa_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, int64_t rows,
                         int64_t D, float eps, int x_f32, int y_f32, void* stream);
 int64_t clipa_layernorm_bwd_workspace(int64_t rows, int64_t D);
 int clipa_layernorm_bwd(const void* x, const float* gamma, const void* dy, const void* dres, void* dx,
                         float* dgamma, float* dbeta, int64_t rows, int64_t D, float eps, int x_f32,
                         int y_f32, void* workspace, int64_t workspace_bytes, void* stream);
+int clipa_layernorm_bwd_y(const void* x, const float* gamma, const float* beta, const void* dy, const void* dres, void* dx,
+                          void* y, float* dgamma, float* dbeta, int64_t rows, int64_t D, float eps, int x_f32,
+                          int y_f32, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* softmax(q.k^T * scale + mask).v per (batch, head); q/k/v are column blocks of the packed projection
  * output (row stride ld_qkv), out is [B*L, H*dh] (row stride ld_o). causal = additive triu(1)*-inf mask.

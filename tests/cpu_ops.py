@@ -89,13 +89,15 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=None):
     return O.layer_norm(x.float(), gamma, beta, eps).to(out_dtype or x.dtype)
 
 
-def layernorm_bwd(x, gamma, dy, dres=None, eps=1e-5):
+def layernorm_bwd(x, gamma, dy, dres=None, eps=1e-5, beta=None):
     xr = x.float().detach().requires_grad_(True)
     g = gamma.detach().clone().requires_grad_(True)
     b = torch.zeros_like(g, requires_grad=True)
     with torch.enable_grad():
         O.layer_norm(xr, g, b, eps).backward(dy.float())
     dx = xr.grad + (dres.float() if dres is not None else 0)
+    if beta is not None:      # the emitting form: + LayerNorm(x), exactly what layernorm_fwd returns
+        return dx.to(x.dtype), g.grad, b.grad, layernorm_fwd(x, gamma, beta, eps, out_dtype=dy.dtype)
     return dx.to(x.dtype), g.grad, b.grad
 
 

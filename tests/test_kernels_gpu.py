@@ -352,6 +352,11 @@ def test_layernorm_row_counts(rows, D):
     check("dbeta", db, br.grad, 1e-4, 2e-3 * scale)
     dx2, dw2, db2 = ops().layernorm_bwd(x.to(DEV), w.to(DEV), dy.to(DEV), dres.to(DEV), 1e-5)
     assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2)      # fixed summation order
+    # the emitting form (clipa_layernorm_bwd_y): same gradients, plus the forward's output bit for bit - a block that recomputes
+    # its LayerNorm outputs in backward takes them from this pass (engine._block_backward)
+    dx3, dw3, db3, y3 = ops().layernorm_bwd(x.to(DEV), w.to(DEV), dy.to(DEV), dres.to(DEV), 1e-5, beta=b.to(DEV))
+    assert torch.equal(dx, dx3) and torch.equal(dw, dw3) and torch.equal(db, db3)
+    assert y3.dtype == y.dtype and torch.equal(y3, y)
 
 
 # -------------------------------------------------------------------------------------------------
