@@ -118,6 +118,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
                                                      void* __restrict__ dx, float* __restrict__ part,
                                                      long rows, int D, float eps, int C,
                                                      const float* __restrict__ beta = nullptr, void* __restrict__ yout = nullptr) {
+  // Contraction is OFF in this kernel and every fused multiply-add is written out: which products hipcc fuses under
+  // -ffp-contract=fast depends on their use counts, which differ between the EMIT and the plain instantiation - and the two must
+  // return the same dx / dgamma / dbeta bit for bit (a block's gradients may not depend on which of its tensors were kept).
+#pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
       const int ch = lane + c * 64;
       if (ch < nchunks) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const float t = v[c][i] - mean; ss += t * t; }
+        for (int i = 0; i < 8; ++i) { const float t = v[c][i] - mean; ss += t * t; }   // (unfused, as ln_fwd_kernel compiles it: same rstd)
       }
     }
     const float rstd = rsqrtf(wave_sum(ss) * invD + eps);
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
           float bt[8], o[8];
           ld8<true, false>(beta, (size_t)ch * 8, bt);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] = (v[c][i] - mean) * rstd * g[c][i] + bt[i];      // ln_fwd_kernel's expression
+          for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf((v[c][i] - mean) * rstd, g[c][i], bt[i]);   // = ln_fwd_kernel's (tested)
           st8<YF32>(yout, (size_t)r * D + (size_t)ch * 8, o);
         }
       }
@@ -183,11 +187,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
         for (int i = 0; i < 8; ++i) {
           const float xh = (v[c][i] - mean) * rstd;
           const float dyv = d[c][i];
-          dg[c][i] += dyv * xh;
+          dg[c][i] = __builtin_fmaf(dyv, xh, dg[c][i]);
           db[c][i] += dyv;
           const float dxh = dyv * g[c][i];
           s1 += dxh;
-          s2 += dxh * xh;
+          s2 = __builtin_fmaf(dxh, xh, s2);
           v[c][i] = xh;      // keep xhat
           d[c][i] = dxh;     // keep dxhat
         }
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
       if (ch < nchunks) {
         float o[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = rstd * (d[c][i] - m1 - v[c][i] * m2);
+        for (int i = 0; i < 8; ++i) o[i] = rstd * __builtin_fmaf(-v[c][i], m2, d[c][i] - m1);
         if (dres) {
           float rr[8];
           ld8<XF32>(dres, (size_t)r * D + (size_t)ch * 8, rr);

@@ -331,7 +331,7 @@ def test_layernorm(D, xdt, ydt):
     check("dx no-res", dx2, xr.grad, tolx, tolx * 4)
 
 
-@pytest.mark.parametrize("rows,D", [(1, 256), (41, 256), (8190, 256), (300001, 256), (9001, 1280)])
+@pytest.mark.parametrize("rows,D", [(1, 256), (41, 256), (8190, 256), (300001, 256), (9001, 1280), (5003, 384), (4099, 768), (70001, 1024)])
 def test_layernorm_row_counts(rows, D):
     """The launch shapes of layernorm.hip: forward = one block per 8 rows (odd tails), backward = one block per C adjacent rows
     (C = 4 ... 128 by row count) whose dgamma / dbeta partials go through the one- or two-pass reduction (<= / > 128 blocks);
