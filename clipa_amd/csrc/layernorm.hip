@@ -165,19 +165,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
       }
     }
     const float rstd = rsqrtf(wave_sum(ss) * invD + eps);
-    if constexpr (EMIT) {
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const int ch = lane + c * 64;
-        if (ch < nchunks) {
-          float bt[8], o[8];
-          ld8<true, false>(beta, (size_t)ch * 8, bt);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf((v[c][i] - mean) * rstd, g[c][i], bt[i]);   // = ln_fwd_kernel's (tested)
-          st8<YF32>(yout, (size_t)r * D + (size_t)ch * 8, o);
-        }
-      }
-    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -212,6 +199,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
           for (int i = 0; i < 8; ++i) o[i] += rr[i];
         }
         st8<XF32>(dx, (size_t)r * D + (size_t)ch * 8, o);
+        if constexpr (EMIT) {      // v holds xhat = (x - mean) * rstd: y = xhat * gamma + beta, ln_fwd_kernel's expression (tested)
+          float bt[8];
+          ld8<true, false>(beta, (size_t)ch * 8, bt);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf(v[c][i], g[c][i], bt[i]);
+          st8<YF32>(yout, (size_t)r * D + (size_t)ch * 8, o);
+        }
       }
     }
   }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/traffic.json from a PMC summary (tools/pmc_summary.py output of `tools/gpu_round4.sh pmcbench`):
+"""profiles/traffic.json from a PMC summary (tools/pmc_summary.py output of `tools/gpu_round5.sh pmcbench`):
 
     python tools/make_traffic_json.py gpurun_out/pmcbench_summary.txt "what was measured"
 
@@ -39,7 +39,7 @@ def main():
         "kernel_source_sha16": kernel_source_sha16(),
         "measured": note,
         "workload": {"model": "ViT-L-16", "image_size": 224, "ctx": 77, "batch": 4096, "precision": "bf16"},   # bench.py's default = what the PMC stage runs
-        "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, counters only; tools/gpu_round4.sh stage pmcbench) over "
+        "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, counters only; tools/gpu_round5.sh stage pmcbench) over "
                   "`python bench.py --steps 1 --warmup 0 --keep-blocks <the plan named under 'measured'>`, dispatch-weighted mean over the %d gemm_nta_kernel dispatches of the "
                   "step; read side doubled per MI355X_MICROARCH.md (FETCH_SIZE reports 1/2 of wide coalesced reads on gfx950), WRITE_SIZE taken as "
                   "is.  Fabric-side counters: Infinity-Cache hits are included; the excess over the algorithmic bytes is operand panels re-fetched "
