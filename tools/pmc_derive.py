@@ -37,8 +37,8 @@ for k, c in per.items():
         xcd = c["GRBM_GUI_ACTIVE"] / 8
         if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
             out.append(f"MFMA busy {100 * c['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * xcd):.1f} % of SIMD cycles")
-        d = next((v for kk, v in dur.items() if kk.startswith(k[:60]) or k.startswith(kk[:60])), None)
-        if d:
+        d = None if " grid=" in k else next((v for kk, v in dur.items() if kk.startswith(k[:60]) or k.startswith(kk[:60])), None)
+        if d:      # (rows split by launch grid - tools/pmc_summary.py PMC_BY_GRID - have no duration of their own in the trace summary)
             out.append(f"duration {d:.0f} us (uncounted run) -> clock <= {xcd / d / 1e3:.2f} GHz")
     if c.get("SQ_WAVE_CYCLES"):
         w = c["SQ_WAVE_CYCLES"]
