@@ -389,9 +389,9 @@ def main():
     L_img = (args.image_size // cfg["vision_cfg"]["patch_size"]) ** 2 + 1
     vt, tt = model.visual.transformer, model.transformer
     layers = {"v": cfg["vision_cfg"]["layers"], "t": cfg["text_cfg"]["layers"]}
-    # towers whose last block runs on the pooled rows only (engine.LastBlockFn; bf16 engines): class-token image towers, text
-    image_pruned = args.precision != "fp8" and model.visual._pool_mode() == ops.POOL_FIRST
-    text_pruned = args.precision != "fp8"
+    # towers whose last block runs on the pooled rows only (engine.LastBlockFn): class-token image towers, every text tower
+    image_pruned = model.visual._pool_mode() == ops.POOL_FIRST
+    text_pruned = True
     pruned_last = tuple(tw for tw, on in (("v", image_pruned), ("t", text_pruned)) if on)
     warm = args.warmup
     total_mem = torch.cuda.get_device_properties(dev).total_memory

@@ -304,14 +304,15 @@ class LastBlockFn(torch.autograd.Function):
     Every other row of the last block's output is dead - nothing reads it, its gradient is exactly zero - so only the keys and
     values need all tokens: LN1, the in-projection and attention run on every row, the out-projection, LN2 and the MLP on the B
     pooled rows (the reference computes all B * L of them and the pooling discards them; same kind of identity as taking the
-    pooled row before ln_post, SURVEY 8a identity 8).  Forward values of the pooled rows and all gradients are those of the full
+    pooled row before ln_post, SURVEY 8a identity 8).  fp8 engines (round 5): the token-level part - LN1, in-projection and its
+    input gradient - runs on the fp8 path like every other block; the B pooled rows (0.5 % of a block's rows) run the bf16 GEMMs.  Forward values of the pooled rows and all gradients are those of the full
     block (zero rows add nothing to a weight gradient).  `rows`: int64 device tensor [B], row index of the pooled token of each
     sample in x.  The token-level part (qkv, attention output, softmax statistics) is kept or recomputed like any other block's;
     the B-row part is always kept (a few MB)."""
 
     @staticmethod
     def forward(ctx, x, rows, cfg, cache, *params):
-        P = _block_operands(params, cache, False)
+        P = _block_operands(params, cache, bool(cfg.get("fp8")))
         needs_grad = any(ctx.needs_input_grad)
         # token-level tensors this block keeps: the block's keep set like any other block's ("qkv", "a" = attention output +
         # softmax statistics; the named tiers all hold both); x1 / the pre-activation exist for the B pooled rows only
@@ -334,6 +335,9 @@ class LastBlockFn(torch.autograd.Function):
 
     @staticmethod
     def _qkv(x, P, cfg):
+        if cfg.get("fp8"):
+            _, q1, s1 = ops.layernorm_fwd_q8(x, P["ln1_w"], P["ln1_b"], cfg["eps"], want_bf16=False)
+            return _lin8(q1, s1, P, "in")
         return ops.gemm_nt(ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"]), P["w_in"], P["b_in"])
 
     @staticmethod
@@ -347,7 +351,7 @@ class LastBlockFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, rows = ctx.saved_tensors
         cfg, params = ctx.cfg, ctx.params
-        P = _block_operands(params, ctx.cache, False)
+        P = _block_operands(params, ctx.cache, bool(cfg.get("fp8")))
         a_c, x1, h2, hpre, g = ctx.small
         ctx.small = None
         dy = dy.contiguous()
@@ -365,7 +369,7 @@ class LastBlockFn(torch.autograd.Function):
             a, stats = a2, stats2
         dqkv = _attn_bwd(qkv, a, ops.scatter_rows(da_c, rows, M), stats, cfg)
         del qkv, a, stats
-        dh1 = ops.gemm_nt(dqkv, P["wt_in"])
+        dh1 = _dlin8(dqkv, P, "in", cfg) if cfg.get("fp8") else ops.gemm_nt(dqkv, P["wt_in"])
         h1 = ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"])
         d_w_in, d_b_in = ops.gemm_tn(dqkv, h1, P["dt_w_in"], want_colsum=True)
         del dqkv, h1

@@ -170,7 +170,7 @@ class Transformer(nn.Module):
 
     def run(self, x, B, L, causal, cache, varlen=None, pooled_rows=None):
         """pooled_rows (int64 device [B]): the head reads only these rows of the tower's output - the last block then computes and
-        returns only them ([B, D]; engine.LastBlockFn).  bf16 engines only; the fp8 engine runs the full last block and gathers."""
+        returns only them ([B, D]; engine.LastBlockFn)."""
         if causal and self.width // self.heads > 80:
             _unsupported(f"causal attention with head dim {self.width // self.heads} (the wide heads are compiled for image towers)")
         base = {"B": B, "L": L, "H": self.heads, "causal": bool(causal), "act": self.act, "eps": 1e-5,
@@ -187,7 +187,7 @@ class Transformer(nn.Module):
                 ks = frozenset(t for t, n in self.keep_counts.items() if i >= len(self.resblocks) - n) | engine.KEEP_SETS.get(cfg["keep"] if cfg is not base else None, frozenset())
                 if ks:
                     cfg = dict(base, keep_this=True, keep=ks)
-            if i == last and pooled_rows is not None and not self.fp8:
+            if i == last and pooled_rows is not None:
                 return engine.LastBlockFn.apply(x, pooled_rows, cfg, cache, *blk.param_tuple())
             x = engine.ResBlockFn.apply(x, cfg, cache, *blk.param_tuple())
         return x if pooled_rows is None else engine.TokenDropFn.apply(x, pooled_rows)
