@@ -137,9 +137,8 @@ __global__ __launch_bounds__((64 * attn_waves<NKT, DH>()), HD<DH>::WGS) void att
   const int slot = wave_wg / WPH, wave = wave_wg % WPH;
   char* img0 = smem + slot * (2 * LP * RB + 3 * LP * 4);
   char* img1 = img0 + LP * RB;
-  float* sM = (float*)(img0 + 2 * LP * RB);
-  float* sL = sM + LP;
-  float* sD = sL + LP;
+  float* sM = (float*)(img0 + 2 * LP * RB);                      // m' = c rowmax + log2 rowsum per query (round 5: one exponent offset)
+  float* sD = sM + 2 * LP;                                       // D = <dO, O> per query  ([LP, 2 LP): free since the statistics folded)
   constexpr bool STAGE = bwd_stages<NKT, DH>();                  // whole-row stores through 4 KB of LDS per wave
   char* stage = smem + HPW * (2 * LP * RB + 3 * LP * 4) + wave_wg * Stg<DH>::BYTES;
   const int l31 = lane & 31, hi = lane >> 5, q16 = (lane >> 4) & 1, i16 = lane & 15;
