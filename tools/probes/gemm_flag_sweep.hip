@@ -30,7 +30,9 @@ int main(int argc, char** argv) {
   struct Case { long M, N, K; int epi; const char* name; };
   const Case cases[] = {{806912, 4096, 1024, 0, "bias"}, {806912, 4096, 1024, 1, "gelu"}, {806912, 4096, 1024, 3, "dact"},
                         {806912, 3072, 1024, 0, "bias"}, {806912, 1024, 4096, 2, "add"}, {806912, 1024, 4096, 0, "bias"},
-                        {806912, 1024, 3072, 0, "bias"}, {806912, 1024, 1024, 2, "add"}, {315392, 3072, 768, 1, "gelu"}};
+                        {806912, 1024, 3072, 0, "bias"}, {806912, 1024, 1024, 2, "add"}, {315392, 3072, 768, 1, "gelu"},
+                        {315392, 2304, 768, 0, "bias"}, {315392, 768, 3072, 2, "add"}, {315392, 768, 3072, 0, "bias"},
+                        {315392, 768, 2304, 0, "bias"}, {315392, 3072, 768, 3, "dact"}, {315392, 768, 768, 2, "add"}};
   // flags from the command line (decimal or 0x..); default: XCD re-alignment period (bits 26..29: 15 = off, p = every p tiles),
   // each also with the main loop alone (| 2)
   std::vector<int> flags;
@@ -38,7 +40,10 @@ int main(int argc, char** argv) {
   if (flags.empty()) for (int p : {15, 1, 2, 4, 8}) { flags.push_back(p << 26); }
   if (argc <= 1) for (int p : {15, 2, 4}) flags.push_back((p << 26) | 2);
   unsigned long long* d_sum; CK(hipMalloc(&d_sum, 8));
+  const int from = getenv("FLAGSWEEP_FROM") ? atoi(getenv("FLAGSWEEP_FROM")) : 0;
+  int case_no = 0;
   for (const Case& s : cases) {
+    if (case_no++ < from) continue;
     unsigned short *A, *B, *C, *aux = nullptr; float* bias;
     CK(hipMalloc(&A, (size_t)s.M * s.K * 2)); CK(hipMalloc(&B, (size_t)s.N * s.K * 2)); CK(hipMalloc(&C, (size_t)s.M * s.N * 2)); CK(hipMalloc(&bias, s.N * 4));
     if (s.epi >= 2) { CK(hipMalloc(&aux, (size_t)s.M * s.N * 2)); fill_bf16<<<2048, 256, 0, st>>>(aux, (size_t)s.M * s.N, 3u, 1.0f); }
