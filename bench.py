@@ -2,6 +2,7 @@
 """bench.py - image-text pairs/sec of the full CLIP training step on N MI355X of one node.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          # N > 1 without a launcher: re-executes itself under torch.distributed.run
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -190,6 +191,20 @@ def cpu_baseline(cfg, S, ctx, sample_pairs, threads):
                       f"oracle/clip_oracle.py on torch CPU ops"}
 
 
+def self_launch_argv(n_gpus, script_args, port=None):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: the argv this process re-executes itself with - one rank per GPU
+    under torch.distributed.run on this node, rendezvous on 127.0.0.1 (the reference's `torchrun --nproc_per_node 8`,
+    scripts/exp/gpu/vit_l16/i37_t8_pretrain.sh:1).  The torchrun form of the docstring keeps working: it sets WORLD_SIZE, and a
+    process that finds WORLD_SIZE set never re-executes."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(script_args)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -248,14 +263,21 @@ def main():
     ap.add_argument("--cpu-timeout", type=int, default=240)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become one (same arguments, one rank per GPU); never returns
+        argv = self_launch_argv(args.gpus, sys.argv[1:])
+        print("bench.py: --gpus %d without a launcher, re-executing as: %s" % (args.gpus, " ".join(argv)), file=sys.stderr, flush=True)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("OMP_NUM_THREADS", "8")
+        os.execv(argv[0], argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        print(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; pass --nproc-per-node {args.gpus}", file=sys.stderr)
         sys.exit(2)
     if not torch.cuda.is_available():
-        print("bench.py: no GPU visible - the MI355X engine has no CPU fallback", file=sys.stderr)
+        print(f"bench.py (rank {rank} of {world}): no GPU visible - the MI355X engine has no CPU fallback", file=sys.stderr)
         sys.exit(2)
     if args.alloc_conf:
         torch.cuda.memory._set_allocator_settings(args.alloc_conf)

@@ -13,8 +13,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libclipa_hip.so")
-SOURCES = ["gemm_nt.hip", "gemm_nta.hip", "gemm_tn.hip", "gemm_tna.hip", "gemm_f8.hip", "gemm_f8a.hip", "quant.hip", "simce.hip", "layernorm.hip", "attention.hip", "attention_wide.hip", "misc.hip", "augment.hip", "runtime.hip"]
-AUDITED = ("gemm_nta.hip", "gemm_tna.hip", "gemm_f8a.hip")          # sources whose device assembly clipa_amd/isa_audit.py checks
+SOURCES = ["gemm_nt.hip", "gemm_nta.hip", "gemm_tn.hip", "gemm_tna.hip", "gemm_tn8.hip", "gemm_f8.hip", "gemm_f8a.hip", "quant.hip", "simce.hip", "layernorm.hip", "attention.hip", "attention_wide.hip", "misc.hip", "augment.hip", "runtime.hip"]
+AUDITED = ("gemm_nta.hip", "gemm_tna.hip", "gemm_f8a.hip", "gemm_tn8.hip")          # sources whose device assembly clipa_amd/isa_audit.py checks
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", CSRC, "-I", os.path.join(ROOT, "include"),
          "-Wno-unused-result", "-ffp-contract=fast"]

@@ -352,5 +352,8 @@ int nta_launch(const NTArgs& a, int dev, int num_cu, int sched, hipStream_t st);
 // gemm_tna.hip: the same structure for the weight-gradient product (clipa_gemm_tn dispatches to it)
 bool tna_eligible(const TNArgs& a);
 int tna_launch(const TNArgs& a, int dev, dim3 grid, int sched, hipStream_t st);
+// gemm_tn.hip: work order and split-M slice count of the weight-gradient kernels (shared with the fp8 one, gemm_tn8.hip)
+bool tn_per_xcd(long M, long R, long C);
+long tn_slices(long M, long R, long C, int num_cu, bool per_xcd);
 
 }  // namespace clipa_gemm

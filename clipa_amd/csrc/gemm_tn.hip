@@ -390,6 +390,8 @@ int ensure_tn_attrs(int dev) {
   return g_tn_rc[dev];
 }
 
+}  // namespace
+
 // Work order.  Slice-per-XCD (an XCD's workgroups all read the same M rows: fabric reads drop from ~2.2x to ~1.2x the
 // operand bytes) is +1..10 % on the square and tall products and -4..-8 % on the narrow-P / wide-Q one (the c_proj weight
 // gradient: 1024 x 4096, 1280 x 5120, the text tower's 768 x 3072), which keeps the tile-per-XCD order with its fewer,
@@ -436,7 +438,6 @@ long tn_slices(long M, long R, long C, int num_cu, bool per_xcd) {
   return S;
 }
 
-}  // namespace
 }  // namespace clipa_gemm
 
 using namespace clipa_gemm;

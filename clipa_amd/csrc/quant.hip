@@ -11,6 +11,10 @@
 #include "stream.h"
 #include "clipa_hip.h"
 
+#ifndef LN_Q8_BLOCK_CAP
+#define LN_Q8_BLOCK_CAP 8192                      // A/B knob (tools/stream_lib_ab.py)
+#endif
+
 namespace {
 
 template <int FMT>
@@ -191,9 +195,6 @@ extern "C" int clipa_layernorm_fwd_q8(const void* x, const float* gamma, const f
   // 8192 blocks striding the rows: at 806 912 x 1024 / 526 336 x 1280 / 157 696 x 1280 the persistent 2048 blocks of rounds
   // 2-3 take 0.827 / 0.733 / 0.221 ms, 8192 blocks 0.679 / 0.706 / 0.218, a one-shot grid 0.722 / 0.862 / 0.256 (gamma and
   // beta are re-read by every wave: 4x the row bytes) - profiles/r04_stream_kernels_old_vs_new_lib.jsonl
-#ifndef LN_Q8_BLOCK_CAP
-#define LN_Q8_BLOCK_CAP 8192                      // A/B knob (tools/stream_lib_ab.py)
-#endif
   long blocks = (rows + 3) / 4;
   if (blocks > LN_Q8_BLOCK_CAP) blocks = LN_Q8_BLOCK_CAP;
   const dim3 grid((unsigned)blocks), block(256);
@@ -204,6 +205,166 @@ extern "C" int clipa_layernorm_fwd_q8(const void* x, const float* gamma, const f
   else if (D <= 1536) hipLaunchKernelGGL((ln_fwd_q8_kernel<3>), grid, block, 0, st, xp, gamma, beta, (char*)y, (char*)q, dq, (long)rows, (int)D, eps);
   else hipLaunchKernelGGL((ln_fwd_q8_kernel<4>), grid, block, 0, st, xp, gamma, beta, (char*)y, (char*)q, dq, (long)rows, (int)D, eps);
   return clipa_check_launch("layernorm_fwd_q8");
+}
+
+// ---- operands of the fp8 weight-gradient GEMM (gemm_tn8.hip) --------------------------------------------------------------
+// dW = sum_m dY[m,:]^T X[m,:] reduces over tokens, so a per-token scale cannot leave the product: the activation operand absorbs
+// the gradient's row scale ds[m] before it is quantised, Q8[m,:] = e4m3(ds[m] * X[m,:] / t), with one scalar
+// t = max_m ds[m] * sx[m] (sx = the activation's own row scale, max|X[m,:]| / 448: |Q8| <= 448 without saturation) that stays on
+// the device.  No amax history: recompute reproduces the same bytes.
+namespace {
+
+// out[0] = max_m a[m] * b[m] (b may be NULL = 1); a, b >= 0, so the float order is the order of the bit patterns
+__global__ void rowscale_max_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, b ? a[i] * b[i] : a[i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+__device__ __forceinline__ float inv_or_zero(float t) { return t > 0.f ? 1.0f / t : 0.f; }
+
+// ACT: -1 = none, else the MLP activation of common.h applied to x first
+template <int ACT>
+__global__ void scale_quantize_rows_kernel(const char* __restrict__ x, long ldx, const float* __restrict__ rowscale,
+                                           const float* __restrict__ t_dev, char* __restrict__ q, long ldq, long rows, int nch) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * nch) return;
+  const long r = i / nch;
+  const int ch = (int)(i - r * nch);
+  const float s = rowscale[r] * inv_or_zero(t_dev[0]);
+  float f[8];
+  unpack8(ld_stream<u32x4>(x + ((size_t)r * ldx + (size_t)ch * 8) * 2), f);
+  if (ACT >= 0) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      const f32x2 v = {f[j], f[j + 1]};
+      const f32x2 a = act_fwd2<ACT < 0 ? 0 : ACT>(v);
+      f[j] = a.x;
+      f[j + 1] = a.y;
+    }
+    // the forward's GEMM epilogue rounds the activation to bf16 before anything reads it: the same values here
+    unpack8(pack8(f), f);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] *= s;
+  st_stream<u32x2>(q + (size_t)r * ldq + (size_t)ch * 8, e4m3x8_sat(f));
+}
+
+// LayerNorm (transformer.py:19-34) emitting q = e4m3(bf16(LN(x)) * rowscale[r] / t): ln_fwd_q8_kernel with an external scale
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_q8s_kernel(const char* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ rowscale,
+                                                         const float* __restrict__ t_dev, char* __restrict__ q, long rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long nw = (long)gridDim.x * 4;
+  const int nchunks = D >> 3;
+  float g[NCH][8], bt[NCH][8];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int ch = lane + c * 64;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { g[c][i] = 0.f; bt[c][i] = 0.f; }
+    if (ch < nchunks) {
+      const float4 a = *(const float4*)(gamma + ch * 8), b = *(const float4*)(gamma + ch * 8 + 4);
+      const float4 e = *(const float4*)(beta + ch * 8), h = *(const float4*)(beta + ch * 8 + 4);
+      g[c][0] = a.x; g[c][1] = a.y; g[c][2] = a.z; g[c][3] = a.w; g[c][4] = b.x; g[c][5] = b.y; g[c][6] = b.z; g[c][7] = b.w;
+      bt[c][0] = e.x; bt[c][1] = e.y; bt[c][2] = e.z; bt[c][3] = e.w; bt[c][4] = h.x; bt[c][5] = h.y; bt[c][6] = h.z; bt[c][7] = h.w;
+    }
+  }
+  const float invD = 1.0f / (float)D;
+  const float it = inv_or_zero(t_dev[0]);
+  for (long r = wid; r < rows; r += nw) {
+    float v[NCH][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + c * 64;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[c][i] = 0.f;
+      if (ch < nchunks) {
+        unpack8(ld_stream<u32x4>(x + ((size_t)r * D + (size_t)ch * 8) * 2), v[c]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sum += v[c][i];
+      }
+    }
+    const float mean = wave_sum(sum) * invD;
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunks) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = v[c][i] - mean; ss += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) * invD + eps);
+    const float s = rowscale[r] * it;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunks) {
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (v[c][i] - mean) * rstd * g[c][i] + bt[c][i];
+        unpack8(pack8(o), o);                   // the bf16 rounding of the LayerNorm output the forward GEMM saw
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] *= s;
+        st_stream<u32x2>(q + (size_t)r * D + (size_t)ch * 8, e4m3x8_sat(o));
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int clipa_rowscale_max(const float* a, const float* b, int64_t n, float* out, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) { clipa_set_error("rowscale_max: hipMemsetAsync failed"); return CLIPA_ERR_LAUNCH; }
+  if (n <= 0) return CLIPA_OK;
+  long blocks = (n + 1023) / 1024;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(rowscale_max_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, b, (long)n, (unsigned*)out);
+  return clipa_check_launch("rowscale_max");
+}
+
+extern "C" int clipa_scale_quantize_rows(const void* x, const float* rowscale, const float* t_dev, void* q, int64_t rows, int64_t K,
+                                         int64_t ldx, int64_t ldq, int act, void* stream) {
+  if (rows <= 0) return CLIPA_OK;
+  if (K <= 0 || K % 8 != 0) { clipa_set_error("scale_quantize_rows: K=%ld must be a positive multiple of 8", (long)K); return CLIPA_ERR_ARG; }
+  if (ldx % 8 != 0 || ldq % 8 != 0 || ldx < K || ldq < K) { clipa_set_error("scale_quantize_rows: ldx, ldq must be multiples of 8 and >= K"); return CLIPA_ERR_ARG; }
+  if (act < -1 || act > ACT_QUICK_GELU) { clipa_set_error("scale_quantize_rows: unknown activation %d", act); return CLIPA_ERR_ARG; }
+  if (!rowscale || !t_dev) { clipa_set_error("scale_quantize_rows: rowscale and t are required"); return CLIPA_ERR_ARG; }
+  const long nch = K / 8, total = rows * nch;
+  const long blocks = (total + 255) / 256;
+  if (blocks > 0x7fffffffL) { clipa_set_error("scale_quantize_rows: too many elements"); return CLIPA_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)blocks), block(256);
+#define SQ_LAUNCH(A) hipLaunchKernelGGL((scale_quantize_rows_kernel<A>), grid, block, 0, st, (const char*)x, (long)ldx, rowscale, t_dev, (char*)q, (long)ldq, (long)rows, (int)nch)
+  if (act < 0) SQ_LAUNCH(-1);
+  else if (act == ACT_GELU_ERF) SQ_LAUNCH(ACT_GELU_ERF);
+  else if (act == ACT_GELU_TANH) SQ_LAUNCH(ACT_GELU_TANH);
+  else SQ_LAUNCH(ACT_QUICK_GELU);
+#undef SQ_LAUNCH
+  return clipa_check_launch("scale_quantize_rows");
+}
+
+extern "C" int clipa_layernorm_fwd_q8s(const void* x, const float* gamma, const float* beta, const float* rowscale, const float* t_dev,
+                                       void* q, int64_t rows, int64_t D, float eps, void* stream) {
+  if (rows <= 0) return CLIPA_OK;
+  if (D <= 0 || D % 8 != 0 || D > 2048) { clipa_set_error("layernorm_fwd_q8s: D=%ld must be a multiple of 8 in (0, 2048]", (long)D); return CLIPA_ERR_ARG; }
+  if (!rowscale || !t_dev) { clipa_set_error("layernorm_fwd_q8s: rowscale and t are required"); return CLIPA_ERR_ARG; }
+  long blocks = (rows + 3) / 4;
+  if (blocks > LN_Q8_BLOCK_CAP) blocks = LN_Q8_BLOCK_CAP;
+  const dim3 grid((unsigned)blocks), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const char* xp = (const char*)x;
+  if (D <= 512) hipLaunchKernelGGL((ln_fwd_q8s_kernel<1>), grid, block, 0, st, xp, gamma, beta, rowscale, t_dev, (char*)q, (long)rows, (int)D, eps);
+  else if (D <= 1024) hipLaunchKernelGGL((ln_fwd_q8s_kernel<2>), grid, block, 0, st, xp, gamma, beta, rowscale, t_dev, (char*)q, (long)rows, (int)D, eps);
+  else if (D <= 1536) hipLaunchKernelGGL((ln_fwd_q8s_kernel<3>), grid, block, 0, st, xp, gamma, beta, rowscale, t_dev, (char*)q, (long)rows, (int)D, eps);
+  else hipLaunchKernelGGL((ln_fwd_q8s_kernel<4>), grid, block, 0, st, xp, gamma, beta, rowscale, t_dev, (char*)q, (long)rows, (int)D, eps);
+  return clipa_check_launch("layernorm_fwd_q8s");
 }
 
 // ---- e4m3 pre-activations (the "light8" keep tier; gemm_nta's CLIPA_EPI_ACT_PRE8 / CLIPA_EPI_DACT8 write and read the same bytes) ----

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Static audit of the generated-loop GEMM kernels' ISA (gemm_nta / gemm_tna / gemm_f8a), run by clipa_amd.build on the device
+"""Static audit of the generated-loop GEMM kernels' ISA (gemm_nta / gemm_tna / gemm_f8a / gemm_tn8), run by clipa_amd.build on the device
 assembly hipcc emitted (-save-temps) - part of the package so that a copy of clipa_amd without tools/ still builds.
 
 The accumulators of gemm_nta_kernel live in a[0:255] between the tile's inline-asm statement and the v_accvgpr_read
@@ -123,7 +123,7 @@ def audit(path):
     kernel, in_asm = None, False
     agpr = re.compile(r"(?<![\w.])a\[?\d+")
     for ln, line in enumerate(txt, 1):
-        m = re.match(r"^(_ZN\S*gemm_(?:[nt][nt]a|f8a)_kernel\S*):", line)
+        m = re.match(r"^(_ZN\S*gemm_(?:[nt][nt]a|f8a|tn8)_kernel\S*):", line)
         if m:
             kernel = m.group(1)
             in_asm = False
@@ -148,11 +148,11 @@ def audit(path):
             problems.append(f"{path}:{ln}: compiler-generated AGPR use in {kernel}: {code}")
         if code.startswith("v_accvgpr_write"):
             problems.append(f"{path}:{ln}: compiler-generated v_accvgpr_write in {kernel}: {code}")
-    problems += store_data_races(path, txt, r"^(_ZN\S*gemm_(?:[nt][nt]a|f8a)_kernel\S*):")
+    problems += store_data_races(path, txt, r"^(_ZN\S*gemm_(?:[nt][nt]a|f8a|tn8)_kernel\S*):")
     problems += epilogue_store_counts(path, txt)
     # metadata
     meta = "\n".join(txt)
-    for m in re.finditer(r"\.name:\s+(\S*gemm_(?:[nt][nt]a|f8a)_kernel\S*)\n(.*?)\.wavefront_size", meta, re.S):
+    for m in re.finditer(r"\.name:\s+(\S*gemm_(?:[nt][nt]a|f8a|tn8)_kernel\S*)\n(.*?)\.wavefront_size", meta, re.S):
         name, body = m.group(1), m.group(2)
         for key in ("private_segment_fixed_size", "vgpr_spill_count"):
             v = re.search(rf"\.{key}:\s+(\d+)", body)

@@ -59,6 +59,11 @@ SIGNATURES = {
     "clipa_cast_bf16_to_e4m3": (_I32, [_P, _P, _I64, _P]),
     "clipa_cast_e4m3_to_bf16": (_I32, [_P, _P, _I64, _P]),
     "clipa_activation_fwd_e4m3": (_I32, [_P, _P, _I64, _I32, _P]),
+    "clipa_rowscale_max": (_I32, [_P, _P, _I64, _P, _P]),
+    "clipa_scale_quantize_rows": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _P]),
+    "clipa_layernorm_fwd_q8s": (_I32, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P]),
+    "clipa_gemm_tn_f8_workspace": (_I64, [_I64, _I64, _I64]),
+    "clipa_gemm_tn_f8": (_I32, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _F, _P, _I32, _I32, _P, _I64, _P]),
     "clipa_simce_workspace": (_I64, [_I64, _I64]),
     "clipa_simce_fwd": (_I32, [_P, _P, _I64, _I64, _I64, _I64, _I64, _P, _I64, _P, _P, _P, _I64, _P]),
     "clipa_simce_bwd": (_I32, [_P, _P, _I64, _I64, _I64, _I64, _I64, _P, _I64, _F, _P, _P, _I64, _P, _P, _I64, _P]),
@@ -110,7 +115,7 @@ def debug_set(gemm_nt_variant=0, flags=0):
 
 def last_gemm():
     """Kernel family of this process's last GEMM launch (csrc/internal_hooks.h): 1 gemm_nt2, 2 gemm_nta, 3 gemm_tn2,
-    4 gemm_tn3, 5 gemm_tna, 6 gemm_f8a, 7 gemm_nt_f8_kernel."""
+    4 gemm_tn3, 5 gemm_tna, 6 gemm_f8a, 7 gemm_nt_f8_kernel, 8 gemm_tn8 (four-wave fp8 weight gradient), 9 its byte-gather kernel alone."""
     fn = load().clipa_internal_last_gemm
     fn.restype, fn.argtypes = _I32, []
     return int(fn())

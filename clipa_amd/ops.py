@@ -235,6 +235,75 @@ def gemm_nt_f8(a8, sa, b8, sb, bias=None, *, epi=EPI_NONE, act=ACT_GELU_ERF, aux
     return (out, pre) if want_pre else out
 
 
+def rowscale_max(a, b=None):
+    """f32 device scalar [1] = max_m a[m] * b[m] (b None = 1): the tensor scale t of an fp8 weight-gradient operand."""
+    _chk(a, f32, "a", 1)
+    a = a.contiguous()
+    if b is not None:
+        _chk(b, f32, "b", 1)
+        b = b.contiguous()
+        if b.numel() != a.numel():
+            raise RuntimeError(f"rowscale_max: {a.numel()} vs {b.numel()} rows")
+    out = torch.empty(1, device=a.device, dtype=f32)
+    lib.call("clipa_rowscale_max", _p(a), _p(b), a.numel(), _p(out), _stream())
+    return out
+
+
+def scale_quantize_rows(x, rowscale, t, act=-1):
+    """q[m,:] = e4m3(act(x[m,:]) * rowscale[m] / t[0]) - the activation operand of an fp8 weight gradient (act -1 = none)."""
+    _chk(x, bf16, "x", 2)
+    _chk(rowscale, f32, "rowscale", 1)
+    _chk(t, f32, "t", 1)
+    x, ld = _rowmajor(x)
+    M, K = x.shape
+    if rowscale.numel() != M:
+        raise RuntimeError(f"scale_quantize_rows: {rowscale.numel()} row scales for {M} rows")
+    q = torch.empty((M, K), device=x.device, dtype=u8)
+    with _Timed("scale_quantize_rows", 0.0, 3.0 * M * K, f"{M},{K},act{act}"):
+        lib.call("clipa_scale_quantize_rows", _p(x), _p(rowscale.contiguous()), _p(t), _p(q), M, K, ld, K, int(act), _stream())
+    return q
+
+
+def layernorm_fwd_q8s(x, gamma, beta, rowscale, t, eps=1e-5):
+    """q[m,:] = e4m3(LayerNorm(x)[m,:] * rowscale[m] / t[0]): the LayerNorm output as the activation operand of an fp8 weight gradient."""
+    _chk(x, bf16, "x")
+    _chk(gamma, f32, "gamma", 1)
+    _chk(beta, f32, "beta", 1)
+    _chk(rowscale, f32, "rowscale", 1)
+    _chk(t, f32, "t", 1)
+    x = x.contiguous()
+    D = x.shape[-1]
+    rows = x.numel() // D
+    if rowscale.numel() != rows:
+        raise RuntimeError(f"layernorm_fwd_q8s: {rowscale.numel()} row scales for {rows} rows")
+    q = torch.empty(x.shape, device=x.device, dtype=u8)
+    with _Timed("ln_fwd_q8", 0.0, 3.0 * rows * D, f"{rows},{D},s"):
+        lib.call("clipa_layernorm_fwd_q8s", _p(x), _p(gamma), _p(beta), _p(rowscale.contiguous()), _p(t), _p(q), rows, D, float(eps), _stream())
+    return q
+
+
+def gemm_tn_f8(p8, q8, t=None, alpha=1.0, fmt_p=FMT_E4M3, out_dtype=f32):
+    """out[R,C] = alpha * t[0] * p8[M,R]^T @ q8[M,C]; p8 (fmt_p: e4m3 / e5m2), q8 (e4m3) uint8 tensors of fp8 bytes, t an
+    optional f32 device scalar."""
+    _chk(p8, u8, "p8", 2)
+    _chk(q8, u8, "q8", 2)
+    p8, ldp = _rowmajor(p8)
+    q8, ldq = _rowmajor(q8)
+    M, R = p8.shape
+    M2, C = q8.shape
+    if M != M2:
+        raise RuntimeError(f"gemm_tn_f8: M mismatch {M} vs {M2}")
+    if t is not None:
+        _chk(t, f32, "t", 1)
+    wsb = lib.query("clipa_gemm_tn_f8_workspace", M, R, C)
+    ws = torch.empty(max(wsb, 4) // 4, device=p8.device, dtype=f32)
+    out = torch.empty((R, C), device=p8.device, dtype=out_dtype)
+    with _Timed("gemm_tn_f8", 2.0 * M * R * C, 1.0 * M * (R + C) + out.element_size() * R * C, f"{M},{R},{C}"):
+        lib.call("clipa_gemm_tn_f8", _p(p8), _p(q8), _p(out), M, R, C, ldp, ldq, float(alpha), _p(t), int(fmt_p),
+                 1 if out_dtype == bf16 else 0, _p(ws), wsb, _stream())
+    return out
+
+
 def gemm_tn(p, q, out_dtype=f32, want_colsum=False):
     """out[R,C] = p[M,R]^T @ q[M,C]; p, q bf16.  want_colsum: also return sum_m p[m,:] (f32 [R])."""
     _chk(p, bf16, "p", 2)

@@ -86,6 +86,29 @@ int clipa_gemm_nt_f8(const void* A8, const void* B8, const float* scale_a, const
 int clipa_layernorm_fwd_q8(const void* x, const float* gamma, const float* beta, void* y, void* q, float* dq,
                            int64_t rows, int64_t D, float eps, void* stream);
 
+/* fp8 WEIGHT gradients (round 6; same call sites as clipa_gemm_tn: the autograd transposes of nn.Linear / in-proj / out-proj,
+ * transformer.py:209,217-219,234).  The reduction of dW = dY^T . X runs over tokens, so a per-token scale cannot be factored out:
+ * P8 is the row-quantised gradient the input-gradient GEMM already consumes (clipa_quantize_rows: dY[m,:] ~ ds[m] * P8[m,:]),
+ * the activation operand absorbs ds before it is quantised, Q8[m,:] = e4m3(ds[m] * X[m,:] / t), t = max_m ds[m] * sx[m] with
+ * sx the activation's own row scale of the forward pass (|Q8| <= 448, nothing saturates), and dW = t * P8^T . Q8.
+ * clipa_rowscale_max: out[0] = max_m a[m] * b[m] (b NULL = 1; a, b >= 0) - the scalar t, kept on the device.
+ * clipa_scale_quantize_rows: q[m,:] = e4m3(act(x[m,:]) * rowscale[m] / t[0]) (act -1 = none, else the MLP activation applied and
+ * rounded to bf16 first: the re-materialised gelu(h) of transformer.py:217-219); x bf16, t device scalar (0 -> zeros).
+ * clipa_layernorm_fwd_q8s: the same for x -> LayerNorm(x) (transformer.py:19-34; bf16-rounded as clipa_layernorm_fwd writes it).
+ * clipa_gemm_tn_f8: out[R,C] = alpha * alpha_dev[0] * sum_m P8[m,R] * Q8[m,C] on v_mfma_f32_16x16x128_f8f6f4, fp32 accumulation
+ * in split-M slabs + a fixed-order reduce; fmt_p 0 = e4m3 / 1 = e5m2 gradient bytes, Q8 e4m3; alpha_dev may be NULL (= 1);
+ * out f32 or bf16.  R, C % 8 == 0.  Whole 256 x 256 tiles of 16-byte-aligned operands (base, ldp, ldq in bytes) run on the
+ * four-wave kernel of gemm_tn8.hip; rows beyond its slices, and every other shape, on a byte-gather kernel. */
+int clipa_rowscale_max(const float* a, const float* b, int64_t n, float* out, void* stream);
+int clipa_scale_quantize_rows(const void* x, const float* rowscale, const float* t_dev, void* q, int64_t rows, int64_t K,
+                              int64_t ldx, int64_t ldq, int act, void* stream);
+int clipa_layernorm_fwd_q8s(const void* x, const float* gamma, const float* beta, const float* rowscale, const float* t_dev,
+                            void* q, int64_t rows, int64_t D, float eps, void* stream);
+int64_t clipa_gemm_tn_f8_workspace(int64_t M, int64_t R, int64_t C);
+int clipa_gemm_tn_f8(const void* P8, const void* Q8, void* out, int64_t M, int64_t R, int64_t C, int64_t ldp, int64_t ldq,
+                     float alpha, const float* alpha_dev, int fmt_p, int out_bf16, void* workspace, int64_t workspace_bytes,
+                     void* stream);
+
 /* F.layer_norm over the last dim, eps inside sqrt, affine (transformer.py:19-34). x/dx share a dtype
  * (x_f32), y/dy share a dtype (y_f32). bwd: dx = LN'(dy) [+ dres]; dgamma, dbeta f32 [D].
  * clipa_layernorm_bwd_y: the same backward that also writes y = LayerNorm(x) (dtype of dy), bit for bit what

@@ -332,3 +332,108 @@ def test_fp8_e5m2_gradient_operand_and_factory():
     if m2 is not None:
         assert m2.visual.transformer.fp8 and m2.transformer.fp8
         assert m2.visual.transformer.resblocks[0].mlp.c_fc.weight.dtype == torch.bfloat16
+
+
+# ---- fp8 weight gradients (round 6: clipa_gemm_tn_f8 and the operands it takes) ---------------------------------------------
+def _tn8_operands(M, R, C, fmt_p, seed):
+    """Random fp8 bytes of both operands (every finite code, asymmetric) + their fp64 product."""
+    dt_p = F8[fmt_p][0]
+    p = (rnd(M, R, seed=seed, dtype=f32) * torch.exp(rnd(M, 1, seed=seed + 1, dtype=f32))).to(dt_p)
+    q = (rnd(M, C, seed=seed + 2, dtype=f32) * 3.0 + 0.25).to(torch.float8_e4m3fn)
+    ref = p.double().T @ q.double()
+    return p.view(torch.uint8), q.view(torch.uint8), ref
+
+
+@pytest.mark.parametrize("M,R,C", [(128, 16, 16), (300, 72, 40), (1000, 264, 136), (515, 768, 256), (1028, 1280, 256)])
+def test_gemm_tn_f8_generic_shapes(M, R, C):
+    """Any shape runs on the byte-gather kernel: every element against the fp64 product of the same bytes (fp32 accumulation
+    is the only difference), transposition-detecting (R != C, asymmetric data)."""
+    o = ops()
+    p8, q8, ref = _tn8_operands(M, R, C, 0, seed=M + R)
+    out = o.gemm_tn_f8(p8.to(DEV), q8.to(DEV))
+    check("tn f8 generic", out, ref, 1e-3, ref.abs().max().item() * 3e-4)     # the matrix pipe sums a 128-term dot product with aligned, truncated addends
+    t = torch.tensor([0.375], device=DEV)
+    outb = o.gemm_tn_f8(p8.to(DEV), q8.to(DEV), t=t, alpha=2.0, out_dtype=bf16)
+    check("tn f8 generic, alpha x t, bf16", outb, ref * 0.75, 2 ** -7, ref.abs().max().item() * 2e-3)
+
+
+@pytest.mark.parametrize("fmt_p", [0, 1])
+@pytest.mark.parametrize("M,R,C", [(512, 256, 256), (1024, 512, 256), (4096 + 768, 256, 768), (8192 + 300, 768, 256),
+                                    (65536, 1280, 256)])
+def test_gemm_tn_f8_whole_tiles(M, R, C, fmt_p):
+    """Whole 256 x 256 tiles: the four-wave kernel (tools/gen_gemm_tn8.py) on the sliceable rows + the byte-gather kernel on the
+    remainder - bit-identical to the byte-gather kernel alone per slab order is not required (different split), so both are held
+    to the fp64 product; every schedule of the generator must agree BIT FOR BIT with the default (same MFMA order per slab)."""
+    o = ops()
+    from clipa_amd import lib
+    p8, q8, ref = _tn8_operands(M, R, C, fmt_p, seed=7 * M + R + fmt_p)
+    P, Q = p8.to(DEV), q8.to(DEV)
+    tol = ref.abs().max().item() * 3e-4
+    out = o.gemm_tn_f8(P, Q, fmt_p=fmt_p)
+    assert lib.last_gemm() == 8, "the four-wave kernel did not run"
+    check("tn f8 four-wave", out, ref, 1e-3, tol)
+    again = o.gemm_tn_f8(P, Q, fmt_p=fmt_p)
+    assert torch.equal(out, again), "second launch differs"
+    try:
+        for sel in (1, 2, 3):                                   # schedules 0, 1, 2 (flag bits 26..27)
+            _debug_set(0, sel << 26)
+            alt = o.gemm_tn_f8(P, Q, fmt_p=fmt_p)
+            check(f"tn f8 schedule {sel - 1}", alt, ref, 1e-3, tol)
+    finally:
+        _debug_set(0, 0)
+
+
+def test_rowscale_max_and_scaled_quantisers():
+    """The activation operand of an fp8 weight gradient: q = e4m3(act(x) * rowscale / t) with t = max(rowscale * sx) - against
+    torch's own cast of the same fp32 expression (ties may flip on the scale rounding), never saturating, zero t -> zeros."""
+    o = ops()
+    M, K = 777, 1280
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).to(bf16)
+    ds = torch.exp(torch.randn(M, generator=g) * 2.0).float()
+    sx = x.float().abs().amax(1) / 448.0
+    t = o.rowscale_max(ds.to(DEV), sx.to(DEV))
+    assert t.shape == (1,) and abs(t.item() - (ds * sx).max().item()) <= 1e-6 * t.item()
+    assert o.rowscale_max(ds.to(DEV)).item() == ds.max().item()
+    q = o.scale_quantize_rows(x.to(DEV), ds.to(DEV), t)
+    want = (x.float() * (ds * (1.0 / t.cpu()))[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn)
+    got = q.cpu().view(torch.float8_e4m3fn).float()
+    assert torch.isfinite(got).all() and got.abs().max().item() <= 448.0
+    assert (q.cpu() == want.view(torch.uint8)).float().mean().item() > 0.999
+    assert got.abs().max().item() >= 416.0, "the largest scaled element must land in the top binade"
+    # the activation variant: gelu(x) rounded to bf16 first (what the forward GEMM's epilogue stored)
+    for act, name in ((0, "gelu_erf"), (1, "gelu_tanh"), (2, "quick_gelu")):
+        qa = o.scale_quantize_rows(x.to(DEV), ds.to(DEV), t, act=act)
+        gx = O.activation(x.double(), name).to(bf16).float()
+        wa = (gx * (ds * (1.0 / t.cpu()))[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn)
+        d = (qa.cpu().view(torch.float8_e4m3fn).float() - wa.float()).abs()
+        assert (d <= 0.0726 * wa.float().abs() + 2 ** -9 + 1e-3 * 448).all(), name        # one e4m3 step (polynomial GELU, bf16 ties)
+    zero = torch.zeros(1, device=DEV)
+    assert (o.scale_quantize_rows(x.to(DEV), ds.to(DEV), zero).view(torch.float8_e4m3fn).float() == 0).all()
+    # LayerNorm variant == LayerNorm (bf16) followed by the plain scaled quantiser, bit for bit
+    gam, bet = rnd(K, seed=1, dtype=f32).to(DEV) + 1.0, rnd(K, seed=2, dtype=f32).to(DEV)
+    y = o.layernorm_fwd(x.to(DEV), gam, bet, 1e-5)
+    sy = y.float().abs().amax(1) / 448.0
+    ty = o.rowscale_max(ds.to(DEV), sy)
+    assert torch.equal(o.layernorm_fwd_q8s(x.to(DEV), gam, bet, ds.to(DEV), ty, 1e-5), o.scale_quantize_rows(y, ds.to(DEV), ty))
+
+
+def test_fp8_weight_gradient_recipe_is_close_to_bf16():
+    """dW = dY^T X through the recipe of engine._wgrad8 (row-quantised gradient, activation absorbing the row scale, one tensor
+    scale) against the fp64 product of the bf16 operands: e4m3 rounding is ~3 % rms per element and averages out over the tokens."""
+    o = ops()
+    M, R, C = 4096, 512, 256
+    g = torch.Generator().manual_seed(9)
+    dy = (torch.randn(M, R, generator=g) * torch.exp(torch.randn(M, 1, generator=g) * 1.5) * 1e-3).to(bf16)
+    x = (torch.randn(M, C, generator=g) * torch.exp(torch.randn(1, C, generator=g) * 0.5)).to(bf16)
+    ref = dy.double().T @ x.double()
+    for fmt in (0, 1):
+        dq, ds = o.quantize_rows(dy.to(DEV), fmt)
+        _, sx = o.quantize_rows(x.to(DEV))
+        t = o.rowscale_max(ds, sx)
+        x8 = o.scale_quantize_rows(x.to(DEV), ds, t)
+        dw = o.gemm_tn_f8(dq, x8, t=t, fmt_p=fmt).double().cpu()
+        rel = ((dw - ref).norm() / ref.norm()).item()
+        cos = torch.nn.functional.cosine_similarity(dw.flatten(), ref.flatten(), dim=0).item()
+        assert rel < (0.06 if fmt == 0 else 0.10) and cos > 0.995, (fmt, rel, cos)
+        assert abs((dw - ref).mean().item()) < 1e-3 * ref.abs().mean().item() + 1e-9 or rel < 0.05

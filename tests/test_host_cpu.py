@@ -3,6 +3,7 @@ C-ABI export table, config registry, and loud failure off-GPU."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -389,3 +390,30 @@ def test_create_model_and_transforms_returns_reference_style_transforms():
     assert f.dtype == torch.float32 and torch.allclose(f, (v.float() / 255 - mean) / std, atol=1e-6)
     assert tuple(tr_f(pil).shape) == (3, 112, 112)
     # the device pipeline applies the same operations: its CPU oracle is pinned to Pillow by tests/test_augment_cpu.py
+
+
+def test_bench_self_launch_argv_and_no_gpu_exit():
+    """`python bench.py --gpus N` (N > 1) without a launcher re-executes itself under torch.distributed.run with the same
+    arguments (the reference starts its ranks with `torchrun --nproc_per_node 8`,
+    scripts/exp/gpu/vit_l16/i37_t8_pretrain.sh:1).  On this GPU-less box the two ranks it starts must fail with the engine's
+    "no GPU visible" message - not with the launcher check's "WORLD_SIZE" complaint - and `--gpus 1` must not re-execute."""
+    import subprocess
+    import bench
+    argv = bench.self_launch_argv(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], port=29411)
+    assert argv[0] == sys.executable and argv[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in argv and "--nnodes=1" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and argv[argv.index("--master-port") + 1] == "29411"
+    i = argv.index(os.path.join(ROOT, "bench.py"))
+    assert argv[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    if torch.cuda.is_available():
+        return
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "re-executing as" in r.stderr and "torch.distributed.run" in r.stderr
+    assert "rank 0 of 2): no GPU visible" in r.stderr or "rank 1 of 2): no GPU visible" in r.stderr
+    assert "WORLD_SIZE=" not in r.stderr
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"],
+                        capture_output=True, text=True, timeout=300, env=env)
+    assert r1.returncode == 2 and "re-executing" not in r1.stderr and "rank 0 of 1): no GPU visible" in r1.stderr
