@@ -41,7 +41,7 @@ template <int FMT>
 __device__ __forceinline__ void row_scales(float amax, float& s, float& dq) {
   const float FMAX = FMT == 0 ? 448.0f : 57344.0f;
   s = amax > 0.f ? FMAX / amax : 1.0f;
-  dq = amax > 0.f ? amax / FMAX : 1.0f;
+  dq = amax > 0.f ? amax / FMAX : 0.0f;      // an all-zero row (padding tokens): zero bytes, zero scale - the fp8 weight gradient's tensor scale is a maximum over these
 }
 
 // NCH = 16-byte chunks (8 bf16) per lane: K <= NCH * 512
@@ -78,6 +78,85 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const char* __restri
       unpack8(v[c], f);
       st_stream<u32x2>(q + (size_t)row * ldq + (size_t)ch * 8, cvt8<FMT>(f, s));
     }
+  }
+}
+
+// quantize_rows_kernel that also sums the COLUMNS of x (the bias gradient of the layer whose input gradient consumes q: the
+// weight-gradient GEMM of the fp8 engine has no bf16 operand to take it from).  Persistent: a wave strides the rows and keeps
+// its column sums in registers; a block adds its four waves through LDS and writes one partial row; colsum_reduce_kernel adds the
+// partial rows in a fixed order (bit-reproducible, no atomics).
+template <int NCH, int FMT>
+__global__ __launch_bounds__(256) void quantize_rows_colsum_kernel(const char* __restrict__ x, long ldx, char* __restrict__ q, long ldq,
+                                                                   float* __restrict__ dq, float* __restrict__ partial, long rows, int K) {
+  __shared__ float red[4][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long wid = (long)blockIdx.x * 4 + wave;
+  const long nw = (long)gridDim.x * 4;
+  const int nchunks = K >> 3;
+  float cs[NCH][8];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cs[c][i] = 0.f;
+  for (long row = wid; row < rows; row += nw) {
+    u32x4 v[NCH];
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + c * 64;
+      v[c] = u32x4{0, 0, 0, 0};
+      if (ch < nchunks) {
+        v[c] = ld_stream<u32x4>(x + ((size_t)row * ldx + (size_t)ch * 8) * 2);
+        float f[8];
+        unpack8(v[c], f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { amax = fmaxf(amax, fabsf(f[i])); cs[c][i] += f[i]; }
+      }
+    }
+    amax = wave_max(amax);
+    float s, d;
+    row_scales<FMT>(amax, s, d);
+    if (lane == 0) dq[row] = d;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunks) {
+        float f[8];
+        unpack8(v[c], f);
+        st_stream<u32x2>(q + (size_t)row * ldq + (size_t)ch * 8, cvt8<FMT>(f, s));
+      }
+    }
+  }
+  float* out = partial + (size_t)blockIdx.x * K;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[wave][lane * 8 + i] = cs[c][i];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 512; e += 256) {
+      const int col = c * 512 + e;                      // chunk (c * 64 + e / 8), element e % 8
+      if (col < K) out[col] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+    }
+  }
+}
+
+// out[col] = sum_b partial[b][col], b ascending inside 16 interleaved groups, the groups combined in order
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int nb, int K) {
+  __shared__ float4 acc[16][16];
+  const int cg = threadIdx.x & 15, sg = threadIdx.x >> 4;      // 16 column quads x 16 row groups
+  const int col = blockIdx.x * 64 + cg * 4;
+  float4 a = {0.f, 0.f, 0.f, 0.f};
+  if (col < K)
+    for (int b = sg; b < nb; b += 16) {
+      const float4 p = *(const float4*)(partial + (size_t)b * K + col);
+      a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+    }
+  acc[sg][cg] = a;
+  __syncthreads();
+  if (sg == 0 && col < K) {
+    for (int g = 1; g < 16; ++g) { const float4 p = acc[g][cg]; a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w; }
+    *(float4*)(out + col) = a;
   }
 }
 
@@ -186,6 +265,55 @@ extern "C" int clipa_quantize_rows(const void* x, void* q, float* dq, int64_t ro
   if ((rows + 3) / 4 > 0x7fffffffL) { clipa_set_error("quantize_rows: too many rows"); return CLIPA_ERR_ARG; }
   return fmt == 0 ? launch_quant<0>(x, q, dq, rows, K, ldx, ldq, (hipStream_t)stream)
                   : launch_quant<1>(x, q, dq, rows, K, ldx, ldq, (hipStream_t)stream);
+}
+
+#ifndef QUANT_COLSUM_BLOCKS
+#define QUANT_COLSUM_BLOCKS 4096                  // persistent blocks of quantize_rows_colsum (A/B knob)
+#endif
+namespace {
+long quant_colsum_blocks(long rows) {
+  long b = (rows + 3) / 4;
+  if (b > QUANT_COLSUM_BLOCKS) b = QUANT_COLSUM_BLOCKS;
+  return b < 1 ? 1 : b;
+}
+template <int FMT>
+int launch_quant_colsum(const void* x, void* q, float* dq, float* colsum, float* partial, int64_t rows, int64_t K, int64_t ldx,
+                        int64_t ldq, hipStream_t st) {
+  const long nb = quant_colsum_blocks(rows);
+  const dim3 grid((unsigned)nb), block(256);
+  const char* xp = (const char*)x;
+  char* qp = (char*)q;
+#define QC_LAUNCH(N) hipLaunchKernelGGL((quantize_rows_colsum_kernel<N, FMT>), grid, block, 0, st, xp, (long)ldx, qp, (long)ldq, dq, partial, (long)rows, (int)K)
+  if (K <= 512) QC_LAUNCH(1);
+  else if (K <= 1024) QC_LAUNCH(2);
+  else if (K <= 1536) QC_LAUNCH(3);
+  else if (K <= 2048) QC_LAUNCH(4);
+  else if (K <= 3072) QC_LAUNCH(6);
+  else if (K <= 4096) QC_LAUNCH(8);
+  else if (K <= 5120) QC_LAUNCH(10);
+  else QC_LAUNCH(16);
+#undef QC_LAUNCH
+  if (int rc = clipa_check_launch("quantize_rows_colsum")) return rc;
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((K + 63) / 64)), dim3(256), 0, st, (const float*)partial, colsum, (int)nb, (int)K);
+  return clipa_check_launch("quantize_rows_colsum_reduce");
+}
+}  // namespace
+
+extern "C" int64_t clipa_quantize_rows_colsum_workspace(int64_t rows, int64_t K) {
+  return quant_colsum_blocks(rows) * K * (int64_t)sizeof(float);
+}
+
+extern "C" int clipa_quantize_rows_colsum(const void* x, void* q, float* dq, float* colsum, int64_t rows, int64_t K, int64_t ldx,
+                                          int64_t ldq, int fmt, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (K <= 0 || K % 8 != 0 || K > 8192) { clipa_set_error("quantize_rows_colsum: K=%ld must be a multiple of 8 in (0, 8192]", (long)K); return CLIPA_ERR_ARG; }
+  if (ldx % 8 != 0 || ldq % 8 != 0 || ldx < K || ldq < K) { clipa_set_error("quantize_rows_colsum: ldx, ldq must be multiples of 8 and >= K"); return CLIPA_ERR_ARG; }
+  if (fmt != 0 && fmt != 1) { clipa_set_error("quantize_rows_colsum: fmt is 0 (e4m3) or 1 (e5m2)"); return CLIPA_ERR_ARG; }
+  if (K % 4 != 0 || !colsum) { clipa_set_error("quantize_rows_colsum: colsum is required"); return CLIPA_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  if (rows <= 0) { (void)hipMemsetAsync(colsum, 0, K * sizeof(float), st); return CLIPA_OK; }
+  if (!workspace || workspace_bytes < clipa_quantize_rows_colsum_workspace(rows, K)) { clipa_set_error("quantize_rows_colsum: workspace too small"); return CLIPA_ERR_ARG; }
+  return fmt == 0 ? launch_quant_colsum<0>(x, q, dq, colsum, (float*)workspace, rows, K, ldx, ldq, st)
+                  : launch_quant_colsum<1>(x, q, dq, colsum, (float*)workspace, rows, K, ldx, ldq, st);
 }
 
 extern "C" int clipa_layernorm_fwd_q8(const void* x, const float* gamma, const float* beta, void* y, void* q, float* dq,

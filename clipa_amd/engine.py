@@ -92,7 +92,7 @@ def _block_forward(x, P, cfg, keep, need_y=True):
     a third of the block's forward FLOPs, and skips the other three GEMMs and attention)."""
     B, L, H, causal, act = cfg["B"], cfg["L"], cfg["H"], cfg["causal"], cfg["act"]
     if cfg.get("fp8"):
-        return _block_forward_fp8(x, P, cfg, keep, need_y)
+        return _block_forward_fp8(x, P, cfg, keep, need_y)[:2]
     # the named tiers are sets of kept tensors; a frozenset names them one by one (round 4: what a byte buys differs per tensor -
     # the e4m3 pre-activation ~1.5 ms per GB, the attention output ~0.94, x1 ~0.91, qkv ~0.79 at ViT-L/16 - so bench.py's planner
     # keeps them independently): "qkv", "a" (with the softmax statistics), "x1", "h" (bf16 pre-activation) or "h8" (e4m3)
@@ -129,19 +129,35 @@ def _lin8(xq, xs, P, name, **kw):
     return ops.gemm_nt_f8(xq, xs, wq, ws, P["b_" + name], **kw)
 
 
-def _dlin8(dy, P, name, cfg, **kw):
-    """fp8 input gradient: quantise the incoming gradient per token, multiply with the cached quantised W^T."""
-    fmt = cfg.get("fp8_grad_fmt", ops.FMT_E4M3)
-    dq, ds = ops.quantize_rows(dy, fmt)
+def _gradq8(dy, cfg):
+    """The incoming gradient of a linear layer as fp8 operand, quantised ONCE per token for both of its products (input gradient
+    and weight gradient), and its column sums = the layer's bias gradient from the same pass: -> (dq, ds, colsum)."""
+    return ops.quantize_rows(dy, cfg.get("fp8_grad_fmt", ops.FMT_E4M3), want_colsum=True)
+
+
+def _dlin8(dq, ds, P, name, cfg, **kw):
+    """fp8 input gradient: the per-token quantised gradient against the cached quantised W^T."""
     wq, ws = P["wt8_" + name]
-    return ops.gemm_nt_f8(dq, ds, wq, ws, None, fmt_a=fmt, **kw)
+    return ops.gemm_nt_f8(dq, ds, wq, ws, None, fmt_a=cfg.get("fp8_grad_fmt", ops.FMT_E4M3), **kw)
 
 
-def _block_forward_fp8(x, P, cfg, keep, need_y=True):
+def _wgrad8(dq, ds, sx, emit, out_dtype, cfg):
+    """fp8 weight gradient dW = dY^T X (round 6).  The reduction runs over tokens, so the per-token scale ds of the quantised
+    gradient cannot leave the product: the activation operand absorbs it before it is quantised, X8[m,:] = e4m3(ds[m] X[m,:] / t),
+    with one device scalar t = max_m ds[m] sx[m] (sx = the activation's own row scale of the forward pass: nothing saturates, no
+    amax history, recompute reproduces the bytes) and dW = t * dq^T X8.  emit(ds, t) -> X8 (the kernel that has X at hand)."""
+    t = ops.rowscale_max(ds, sx)
+    return ops.gemm_tn_f8(dq, emit(ds, t), t=t, fmt_p=cfg.get("fp8_grad_fmt", ops.FMT_E4M3), out_dtype=out_dtype)
+
+
+def _block_forward_fp8(x, P, cfg, keep, need_y=True, scales=None):
     """_block_forward with the four linear layers on the fp8 MFMA path (BASELINE.json configs[3]): the LayerNorms emit the
     e4m3 operand of the GEMM that follows them, the attention output and the MLP activation are quantised per token by
     clipa_quantize_rows; everything between the GEMMs (residual stream, attention, softmax statistics, kept tensors) is
-    bf16 exactly as in the bf16 engine, and the weight gradients stay bf16 GEMMs of bf16 tensors."""
+    bf16 exactly as in the bf16 engine.  -> (y, kept tensors | None, scales): scales = the per-token scales (s1, sa, s2, sg) of
+    the four GEMM inputs (LN1 output, attention output, LN2 output, activation), a few MB that every block keeps - the fp8
+    weight gradients of the backward derive their tensor scale from them (_wgrad8).  need_y=False (the backward-time recompute)
+    produces the pre-activation only: the activation is re-materialised as an fp8 operand there, its scale comes in through `scales`."""
     B, L, H, causal, act = cfg["B"], cfg["L"], cfg["H"], cfg["causal"], cfg["act"]
     if keep == "light8":          # the e4m3 pre-activation copy is an epilogue of the bf16 GEMM only: plain light keep here
         keep = "light"
@@ -150,49 +166,102 @@ def _block_forward_fp8(x, P, cfg, keep, need_y=True):
     full = bool(keep) and keep not in ("light", "medium")
     h1, q1, s1 = ops.layernorm_fwd_q8(x, P["ln1_w"], P["ln1_b"], cfg["eps"], want_bf16=full)
     qkv = _lin8(q1, s1, P, "in")
-    del q1, s1
+    del q1
     a, stats = _attn_fwd(qkv, cfg, bool(keep))
     qa, sa = ops.quantize_rows(a)
     x1 = _lin8(qa, sa, P, "out", epi=ops.EPI_ADD, aux=x)
-    del qa, sa
+    del qa
     h2, q2, s2 = ops.layernorm_fwd_q8(x1, P["ln2_w"], P["ln2_b"], cfg["eps"], want_bf16=full)
-    if keep and keep != "medium":
-        g, hpre = _lin8(q2, s2, P, "fc", epi=ops.EPI_ACT, act=act, want_pre=True)
-    else:
-        g, hpre = _lin8(q2, s2, P, "fc", epi=ops.EPI_ACT, act=act), None
-    del q2, s2
-    y = None
+    y = g = hpre = sg = None
     if need_y:
+        if keep and keep != "medium":
+            g, hpre = _lin8(q2, s2, P, "fc", epi=ops.EPI_ACT, act=act, want_pre=True)
+        else:
+            g = _lin8(q2, s2, P, "fc", epi=ops.EPI_ACT, act=act)
+        del q2
         qg, sg = ops.quantize_rows(g)
         y = _lin8(qg, sg, P, "proj", epi=ops.EPI_ADD, aux=x1)
-        del qg, sg
+        del qg
+    else:
+        hpre = _lin8(q2, s2, P, "fc")                  # bf16(LN2(x1) W^T + b): what the activation epilogue's second output holds
+        del q2
+        sg = scales[3] if scales is not None else ops.quantize_rows(ops.activation_fwd(hpre, act))[1]
+    sc = (s1, sa, s2, sg)
     if keep in ("light", "medium"):
-        return y, (None, qkv, a, stats, x1, None, hpre, None)
+        return y, (None, qkv, a, stats, x1, None, hpre, None), sc
     if keep:
-        return y, (h1, qkv, a, stats, x1, h2, hpre, g)
-    return y, None
+        return y, (h1, qkv, a, stats, x1, h2, hpre, g if full else None), sc
+    return y, None, sc
+
+
+def _fp8_fill_medium(kept, P, cfg):
+    """A "medium" fp8 block kept qkv / attention output / x1: LN2 + the c_fc GEMM again for the pre-activation (bit for bit the
+    forward's)."""
+    h1, qkv, a, stats, x1, h2, hpre, g = kept
+    _, q2, s2 = ops.layernorm_fwd_q8(x1, P["ln2_w"], P["ln2_b"], cfg["eps"], want_bf16=False)
+    hpre = _lin8(q2, s2, P, "fc")
+    return (h1, qkv, a, stats, x1, h2, hpre, g)
+
+
+def _block_backward_fp8(x, dy, box, P, cfg, scales):
+    """Backward of a block in fp8 mode: every matrix product - input gradients AND (round 6) weight gradients - on
+    v_mfma_f32_16x16x128_f8f6f4.  Each incoming gradient is quantised once per token (its column sums = the bias gradient ride
+    the same pass) and feeds both products of its layer; the activation operand of a weight gradient is emitted as e4m3 by the
+    kernel that re-materialises it anyway (LayerNorm, GELU) with the gradient's token scale folded in (_wgrad8)."""
+    act, eps = cfg["act"], cfg["eps"]
+    h1, qkv, a, stats, x1, h2, hpre, g = box.pop()
+    s1, sa, s2, sg = scales
+    dy = dy.contiguous()
+    # y = x1 + c_proj(gelu(hpre))
+    dq, ds, d_b_proj = _gradq8(dy, cfg)
+    emit_g = (lambda r, t: ops.scale_quantize_rows(g, r, t)) if g is not None else (lambda r, t: ops.scale_quantize_rows(hpre, r, t, act=act))
+    d_w_proj = _wgrad8(dq, ds, sg, emit_g, P["dt_w_proj"], cfg)
+    del g
+    dh = _dlin8(dq, ds, P, "proj", cfg, epi=ops.EPI_DACT, act=act, aux=hpre)     # [M,4D]
+    del hpre, dq, ds
+    dq, ds, d_b_fc = _gradq8(dh, cfg)
+    del dh
+    emit_h2 = (lambda r, t: ops.scale_quantize_rows(h2, r, t)) if h2 is not None else \
+        (lambda r, t: ops.layernorm_fwd_q8s(x1, P["ln2_w"], P["ln2_b"], r, t, eps))
+    d_w_fc = _wgrad8(dq, ds, s2, emit_h2, P["dt_w_fc"], cfg)
+    dh2 = _dlin8(dq, ds, P, "fc", cfg)                                            # [M,D]
+    del dq, ds, h2
+    dx1, d_ln2_w, d_ln2_b = ops.layernorm_bwd(x1, P["ln2_w"], dh2, dres=dy, eps=eps)
+    del dh2, x1
+    # x1 = x + out_proj(a)
+    dq, ds, d_b_out = _gradq8(dx1, cfg)
+    d_w_out = _wgrad8(dq, ds, sa, lambda r, t: ops.scale_quantize_rows(a, r, t), P["dt_w_out"], cfg)
+    da = _dlin8(dq, ds, P, "out", cfg)
+    del dq, ds
+    dqkv = _attn_bwd(qkv, a, da, stats, cfg)
+    del da, a, qkv, stats
+    dq, ds, d_b_in = _gradq8(dqkv, cfg)
+    del dqkv
+    emit_h1 = (lambda r, t: ops.scale_quantize_rows(h1, r, t)) if h1 is not None else \
+        (lambda r, t: ops.layernorm_fwd_q8s(x, P["ln1_w"], P["ln1_b"], r, t, eps))
+    d_w_in = _wgrad8(dq, ds, s1, emit_h1, P["dt_w_in"], cfg)
+    dh1 = _dlin8(dq, ds, P, "in", cfg)
+    del dq, ds, h1
+    dx, d_ln1_w, d_ln1_b = ops.layernorm_bwd(x, P["ln1_w"], dh1, dres=dx1, eps=eps)
+    return dx, (d_ln1_w, d_ln1_b, d_w_in, d_b_in, d_w_out, d_b_out, d_ln2_w, d_ln2_b, d_w_fc, d_b_fc, d_w_proj,
+                d_b_proj)
 
 
 def _block_backward(x, dy, box, P, cfg):
-    """box: one-element list holding the intermediates tuple (popped so they can be freed early)."""
+    """box: one-element list holding the intermediates tuple (popped so they can be freed early).  bf16 engines (the fp8 engine:
+    _block_backward_fp8)."""
     B, L, H, causal, act = cfg["B"], cfg["L"], cfg["H"], cfg["causal"], cfg["act"]
     h1, qkv, a, stats, x1, h2, hpre, g = box.pop()
     dy = dy.contiguous()
-    fp8 = bool(cfg.get("fp8"))
-    if not fp8:
-        # tensors the block did not keep are recomputed here, bit for bit as the forward produced them
-        if qkv is None:
-            h1 = ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"])
-            qkv = ops.gemm_nt(h1, P["w_in"], P["b_in"])
-        if a is None:
-            a, stats = _attn_fwd(qkv, cfg, True)
-        if x1 is None:
-            x1 = ops.gemm_nt(a, P["w_out"], P["b_out"], epi=ops.EPI_ADD, aux=x)
-    if hpre is None and fp8:
-        h2, q2, s2 = ops.layernorm_fwd_q8(x1, P["ln2_w"], P["ln2_b"], cfg["eps"], want_bf16=True)
-        g, hpre = _lin8(q2, s2, P, "fc", epi=ops.EPI_ACT, act=act, want_pre=True)
-        del q2, s2
-    elif hpre is None:   # "medium" block: LN2 + c_fc again (one GEMM instead of four + attention)
+    # tensors the block did not keep are recomputed here, bit for bit as the forward produced them
+    if qkv is None:
+        h1 = ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"])
+        qkv = ops.gemm_nt(h1, P["w_in"], P["b_in"])
+    if a is None:
+        a, stats = _attn_fwd(qkv, cfg, True)
+    if x1 is None:
+        x1 = ops.gemm_nt(a, P["w_out"], P["b_out"], epi=ops.EPI_ADD, aux=x)
+    if hpre is None:     # "medium" block: LN2 + c_fc again (one GEMM instead of four + attention)
         h2 = ops.layernorm_fwd(x1, P["ln2_w"], P["ln2_b"], cfg["eps"])
         g, hpre = ops.gemm_nt(h2, P["w_fc"], P["b_fc"], epi=ops.EPI_ACT, act=act, want_pre=True)
     elif g is None:      # "light" block: cheap HBM-bound re-materialisation instead of 4 GEMMs + attention
@@ -201,20 +270,15 @@ def _block_backward(x, dy, box, P, cfg):
     # intermediates, h1 of a block that kept qkv) are written by the LayerNorm BACKWARD pass, which has every row and its
     # statistics in registers anyway (ops.layernorm_bwd(beta=...): bit for bit ln_fwd's output) - one more store per row instead of
     # a second ln_fwd launch over the same rows; the weight gradient of c_fc / the in-projection then follows its LayerNorm
-    # backward instead of preceding it.  The fp8 engine keeps the order of round 4 (its LayerNorms emit e4m3 operands).
-    emit2, emit1 = (h2 is None and not fp8), (h1 is None and not fp8)
-    if h2 is None and fp8:
-        h2 = ops.layernorm_fwd(x1, P["ln2_w"], P["ln2_b"], cfg["eps"])
+    # backward instead of preceding it.
+    emit2, emit1 = h2 is None, h1 is None
     # y = x1 + c_proj(g).  The weight gradient goes first: g ([M, 4D], the largest transient of the block) is released before
     # the GELU-backward GEMM allocates its output of the same size
     d_w_proj, d_b_proj = ops.gemm_tn(dy, g, P["dt_w_proj"], want_colsum=True)
     del g
-    if fp8:
-        dh = _dlin8(dy, P, "proj", cfg, epi=ops.EPI_DACT, act=act, aux=hpre)
-    else:
-        dh = ops.gemm_nt(dy, P["wt_proj"], epi=ops.EPI_DACT, act=act, aux=hpre)     # [M,4D]
+    dh = ops.gemm_nt(dy, P["wt_proj"], epi=ops.EPI_DACT, act=act, aux=hpre)     # [M,4D]
     del hpre
-    dh2 = _dlin8(dh, P, "fc", cfg) if fp8 else ops.gemm_nt(dh, P["wt_fc"])       # [M,D]
+    dh2 = ops.gemm_nt(dh, P["wt_fc"])       # [M,D]
     if emit2:
         dx1, d_ln2_w, d_ln2_b, h2 = ops.layernorm_bwd(x1, P["ln2_w"], dh2, dres=dy, eps=cfg["eps"], beta=P["ln2_b"])
         del dh2, x1
@@ -226,18 +290,16 @@ def _block_backward(x, dy, box, P, cfg):
         dx1, d_ln2_w, d_ln2_b = ops.layernorm_bwd(x1, P["ln2_w"], dh2, dres=dy, eps=cfg["eps"])
         del dh2, x1
     # x1 = x + out_proj(a)
-    da = _dlin8(dx1, P, "out", cfg) if fp8 else ops.gemm_nt(dx1, P["wt_out"])
+    da = ops.gemm_nt(dx1, P["wt_out"])
     d_w_out, d_b_out = ops.gemm_tn(dx1, a, P["dt_w_out"], want_colsum=True)
     dqkv = _attn_bwd(qkv, a, da, stats, cfg)
     del da, a, qkv, stats
-    dh1 = _dlin8(dqkv, P, "in", cfg) if fp8 else ops.gemm_nt(dqkv, P["wt_in"])
+    dh1 = ops.gemm_nt(dqkv, P["wt_in"])
     if emit1:
         dx, d_ln1_w, d_ln1_b, h1 = ops.layernorm_bwd(x, P["ln1_w"], dh1, dres=dx1, eps=cfg["eps"], beta=P["ln1_b"])
         d_w_in, d_b_in = ops.gemm_tn(dqkv, h1, P["dt_w_in"], want_colsum=True)
         del dqkv, h1
     else:
-        if h1 is None:
-            h1 = ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"])
         d_w_in, d_b_in = ops.gemm_tn(dqkv, h1, P["dt_w_in"], want_colsum=True)
         del dqkv, h1
         dx, d_ln1_w, d_ln1_b = ops.layernorm_bwd(x, P["ln1_w"], dh1, dres=dx1, eps=cfg["eps"])
@@ -275,7 +337,13 @@ class ResBlockFn(torch.autograd.Function):
         keep = False
         if needs_grad:
             keep = cfg.get("keep", "light") if (not cfg["recompute"] or cfg.get("keep_this", False)) else False
-        y, inter = _block_forward(x, P, cfg, keep)
+        ctx.scales = None
+        if cfg.get("fp8"):
+            y, inter, scales = _block_forward_fp8(x, P, cfg, keep)
+            if needs_grad:
+                ctx.scales = scales
+        else:
+            y, inter = _block_forward(x, P, cfg, keep)
         ctx.cfg, ctx.cache, ctx.params = cfg, cache, params
         if needs_grad:
             ctx.save_for_backward(x)
@@ -289,9 +357,17 @@ class ResBlockFn(torch.autograd.Function):
         P = _block_operands(params, ctx.cache, bool(cfg.get("fp8")))
         box = [ctx.inter]
         ctx.inter = None
-        if box[0] is None:
-            box[0] = _block_forward(x, P, cfg, True, need_y=False)[1]
-        dx, grads = _block_backward(x, dy, box, P, cfg)
+        if cfg.get("fp8"):
+            scales, ctx.scales = ctx.scales, None
+            if box[0] is None or box[0][6] is None:     # nothing kept / no pre-activation ("medium"): recompute what is missing
+                kept = box[0]
+                box[0] = _block_forward_fp8(x, P, cfg, "light", need_y=False, scales=scales)[1] if kept is None else \
+                    _fp8_fill_medium(kept, P, cfg)
+            dx, grads = _block_backward_fp8(x, dy, box, P, cfg, scales)
+        else:
+            if box[0] is None:
+                box[0] = _block_forward(x, P, cfg, True, need_y=False)[1]
+            dx, grads = _block_backward(x, dy, box, P, cfg)
         grads = tuple(_like_param(g, p) if p.requires_grad else None for g, p in zip(grads, params))
         return (dx, None, None) + grads
 
@@ -320,7 +396,9 @@ class LastBlockFn(torch.autograd.Function):
         if needs_grad and (not cfg["recompute"] or cfg.get("keep_this", False)):
             keep = cfg.get("keep", "light")
             ks = KEEP_SETS.get(keep, keep) if isinstance(keep, (str, frozenset)) else KEEP_SETS["light"]
-        qkv, a, stats = LastBlockFn._tokens(x, P, cfg, "a" in ks)
+        s1_box = [None]
+        qkv, a, stats = LastBlockFn._tokens(x, P, cfg, "a" in ks, box=s1_box)
+        ctx.s1 = s1_box[0] if needs_grad else None
         a_c, x_c = ops.gather_rows(a, rows), ops.gather_rows(x, rows)
         x1 = ops.gemm_nt(a_c, P["w_out"], P["b_out"], epi=ops.EPI_ADD, aux=x_c)
         h2 = ops.layernorm_fwd(x1, P["ln2_w"], P["ln2_b"], cfg["eps"])
@@ -334,16 +412,19 @@ class LastBlockFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    def _qkv(x, P, cfg):
+    def _qkv(x, P, cfg, box=None):
+        """-> qkv; fp8 engines leave the LayerNorm output's per-token scale in box[0] (the weight gradient's tensor scale, _wgrad8)."""
         if cfg.get("fp8"):
             _, q1, s1 = ops.layernorm_fwd_q8(x, P["ln1_w"], P["ln1_b"], cfg["eps"], want_bf16=False)
+            if box is not None:
+                box[0] = s1
             return _lin8(q1, s1, P, "in")
         return ops.gemm_nt(ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"]), P["w_in"], P["b_in"])
 
     @staticmethod
-    def _tokens(x, P, cfg, want_stats, qkv=None):
+    def _tokens(x, P, cfg, want_stats, qkv=None, box=None):
         if qkv is None:
-            qkv = LastBlockFn._qkv(x, P, cfg)
+            qkv = LastBlockFn._qkv(x, P, cfg, box)
         a, stats = _attn_fwd(qkv, cfg, bool(want_stats))
         return qkv, a, stats
 
@@ -369,10 +450,19 @@ class LastBlockFn(torch.autograd.Function):
             a, stats = a2, stats2
         dqkv = _attn_bwd(qkv, a, ops.scatter_rows(da_c, rows, M), stats, cfg)
         del qkv, a, stats
-        dh1 = _dlin8(dqkv, P, "in", cfg) if cfg.get("fp8") else ops.gemm_nt(dqkv, P["wt_in"])
-        h1 = ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"])
-        d_w_in, d_b_in = ops.gemm_tn(dqkv, h1, P["dt_w_in"], want_colsum=True)
-        del dqkv, h1
+        if cfg.get("fp8"):      # token-level products of the block on the fp8 path: input and weight gradient of the in-projection
+            s1, ctx.s1 = ctx.s1, None
+            dq, ds, d_b_in = _gradq8(dqkv, cfg)
+            del dqkv
+            d_w_in = _wgrad8(dq, ds, s1, lambda r, t: ops.layernorm_fwd_q8s(x, P["ln1_w"], P["ln1_b"], r, t, cfg["eps"]),
+                             P["dt_w_in"], cfg)
+            dh1 = _dlin8(dq, ds, P, "in", cfg)
+            del dq, ds
+        else:
+            dh1 = ops.gemm_nt(dqkv, P["wt_in"])
+            h1 = ops.layernorm_fwd(x, P["ln1_w"], P["ln1_b"], cfg["eps"])
+            d_w_in, d_b_in = ops.gemm_tn(dqkv, h1, P["dt_w_in"], want_colsum=True)
+            del dqkv, h1
         # x1 = x[rows] + out_proj(a[rows]): the residual gradient reaches x at the pooled rows only
         dx, d_ln1_w, d_ln1_b = ops.layernorm_bwd(x, P["ln1_w"], dh1, dres=ops.scatter_rows(dx1, rows, M), eps=cfg["eps"])
         grads = (d_ln1_w, d_ln1_b, d_w_in, d_b_in, d_w_out, d_b_out, d_ln2_w, d_ln2_b, d_w_fc, d_b_fc, d_w_proj, d_b_proj)

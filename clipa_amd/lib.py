@@ -59,6 +59,8 @@ SIGNATURES = {
     "clipa_cast_bf16_to_e4m3": (_I32, [_P, _P, _I64, _P]),
     "clipa_cast_e4m3_to_bf16": (_I32, [_P, _P, _I64, _P]),
     "clipa_activation_fwd_e4m3": (_I32, [_P, _P, _I64, _I32, _P]),
+    "clipa_quantize_rows_colsum_workspace": (_I64, [_I64, _I64]),
+    "clipa_quantize_rows_colsum": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _P, _I64, _P]),
     "clipa_rowscale_max": (_I32, [_P, _P, _I64, _P, _P]),
     "clipa_scale_quantize_rows": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _P]),
     "clipa_layernorm_fwd_q8s": (_I32, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P]),

@@ -175,14 +175,21 @@ FMT_E4M3, FMT_E5M2 = 0, 1
 u8 = torch.uint8
 
 
-def quantize_rows(x, fmt=FMT_E4M3):
+def quantize_rows(x, fmt=FMT_E4M3, want_colsum=False):
     """Row-scaled fp8 operand of a bf16 matrix: -> (q uint8 [M,K] holding OCP e4m3 / e5m2 bytes, dq f32 [M]) with
-    x[r,:] ~ dq[r] * fp8(q[r,:])."""
+    x[r,:] ~ dq[r] * fp8(q[r,:]).  want_colsum: also sum_r x[r,:] (f32 [K]; the bias gradient when x is a layer's dY)."""
     _chk(x, bf16, "x", 2)
     x, ld = _rowmajor(x)
     M, K = x.shape
     q = torch.empty((M, K), device=x.device, dtype=u8)
     dq = torch.empty(M, device=x.device, dtype=f32)
+    if want_colsum:
+        cs = torch.empty(K, device=x.device, dtype=f32)
+        wsb = lib.query("clipa_quantize_rows_colsum_workspace", M, K)
+        ws = torch.empty(max(wsb, 4) // 4, device=x.device, dtype=f32)
+        with _Timed("quantize_rows", 0.0, 3.0 * M * K, f"{M},{K},+colsum"):
+            lib.call("clipa_quantize_rows_colsum", _p(x), _p(q), _p(dq), _p(cs), M, K, ld, K, int(fmt), _p(ws), wsb, _stream())
+        return q, dq, cs
     with _Timed("quantize_rows", 0.0, 3.0 * M * K, f"{M},{K}"):
         lib.call("clipa_quantize_rows", _p(x), _p(q), _p(dq), M, K, ld, K, int(fmt), _stream())
     return q, dq

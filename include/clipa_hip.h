@@ -71,7 +71,7 @@ int clipa_gemm_tn(const void* P, const void* Q, void* out, float* colsum_out, in
  * training/params.py:195-200, stops at bf16, so these have no reference counterpart - same call sites as clipa_gemm_nt:
  * the linear layers of a residual block, transformer.py:209,217-219,234, forward and input gradient).
  * clipa_quantize_rows: q[r,:] = fp8(x[r,:] * FMAX / max|x[r,:]|) (x bf16, q bytes; fmt 0 = OCP e4m3, FMAX 448; 1 = e5m2,
- * FMAX 57344), dq[r] = max|x[r,:]| / FMAX (1 for an all-zero row).  K % 8 == 0, K <= 8192.
+ * FMAX 57344), dq[r] = max|x[r,:]| / FMAX (0 for an all-zero row).  K % 8 == 0, K <= 8192.
  * clipa_gemm_nt_f8: C = epi(alpha * scale_a[m] * scale_b[n] * A8 . B8^T + bias[n]) on v_mfma_f32_16x16x128_f8f6f4, fp32
  * accumulation, bf16 C / C2 / aux and the epilogues of clipa_gemm_nt; scale_a [M], scale_b [N] may be NULL (= 1).  Whole-tile
  * shapes (M, N % 256 == 0, K % 256 == 0, K >= 512, e4m3 weights) run on the four-wave kernel of gemm_f8a.hip, bit-identical.
@@ -99,6 +99,12 @@ int clipa_layernorm_fwd_q8(const void* x, const float* gamma, const float* beta,
  * in split-M slabs + a fixed-order reduce; fmt_p 0 = e4m3 / 1 = e5m2 gradient bytes, Q8 e4m3; alpha_dev may be NULL (= 1);
  * out f32 or bf16.  R, C % 8 == 0.  Whole 256 x 256 tiles of 16-byte-aligned operands (base, ldp, ldq in bytes) run on the
  * four-wave kernel of gemm_tn8.hip; rows beyond its slices, and every other shape, on a byte-gather kernel. */
+/* clipa_quantize_rows_colsum: clipa_quantize_rows that also returns colsum[k] = sum_r x[r,k] (f32 [K]) - the bias gradient of the
+ * layer (the column sums of dY: nn.Linear's bias, transformer.py:209,217-219) from the pass that quantises dY for the input-gradient
+ * and weight-gradient GEMMs; fixed summation order.  workspace: per-block partial rows. */
+int64_t clipa_quantize_rows_colsum_workspace(int64_t rows, int64_t K);
+int clipa_quantize_rows_colsum(const void* x, void* q, float* dq, float* colsum, int64_t rows, int64_t K, int64_t ldx, int64_t ldq,
+                               int fmt, void* workspace, int64_t workspace_bytes, void* stream);
 int clipa_rowscale_max(const float* a, const float* b, int64_t n, float* out, void* stream);
 int clipa_scale_quantize_rows(const void* x, const float* rowscale, const float* t_dev, void* q, int64_t rows, int64_t K,
                               int64_t ldx, int64_t ldq, int act, void* stream);

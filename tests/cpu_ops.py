@@ -58,13 +58,36 @@ u8 = torch.uint8
 _F8 = {0: (torch.float8_e4m3fn, 448.0), 1: (torch.float8_e5m2, 57344.0)}
 
 
-def quantize_rows(x, fmt=FMT_E4M3):
+def quantize_rows(x, fmt=FMT_E4M3, want_colsum=False):
     dt, fmax = _F8[fmt]
     xf = x.float()
     amax = xf.abs().amax(dim=1)
     s = torch.where(amax > 0, fmax / amax, torch.ones_like(amax))
-    dq = torch.where(amax > 0, amax / fmax, torch.ones_like(amax))
-    return (xf * s[:, None]).to(dt).view(u8), dq
+    dq = torch.where(amax > 0, amax / fmax, torch.zeros_like(amax))
+    q = (xf * s[:, None]).to(dt).view(u8)
+    return (q, dq, xf.sum(0)) if want_colsum else (q, dq)
+
+
+def rowscale_max(a, b=None):
+    return (a * b if b is not None else a).max().reshape(1).float()
+
+
+def scale_quantize_rows(x, rowscale, t, act=-1):
+    v = x.float()
+    if act >= 0:
+        v = _act(v, act).to(bf16).float()
+    inv = torch.where(t > 0, 1.0 / t, torch.zeros_like(t))
+    return _e4m3(v * (rowscale * inv)[:, None])
+
+
+def layernorm_fwd_q8s(x, gamma, beta, rowscale, t, eps=1e-5):
+    y = layernorm_fwd(x, gamma, beta, eps)
+    return scale_quantize_rows(y.reshape(-1, y.shape[-1]), rowscale, t).reshape(y.shape)
+
+
+def gemm_tn_f8(p8, q8, t=None, alpha=1.0, fmt_p=FMT_E4M3, out_dtype=f32):
+    v = p8.view(_F8[fmt_p][0]).float().T @ q8.view(torch.float8_e4m3fn).float()
+    return (v * (alpha * (float(t) if t is not None else 1.0))).to(out_dtype)
 
 
 def layernorm_fwd_q8(x, gamma, beta, eps=1e-5, want_bf16=False):

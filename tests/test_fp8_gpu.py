@@ -34,7 +34,7 @@ def cpu_quantize(x, fmt):
     xf = x.float()
     amax = xf.abs().amax(dim=1)
     s = torch.where(amax > 0, torch.tensor(fmax) / amax, torch.ones_like(amax))
-    dq = torch.where(amax > 0, amax / fmax, torch.ones_like(amax))
+    dq = torch.where(amax > 0, amax / fmax, torch.zeros_like(amax))
     return (xf * s[:, None]).to(dt), dq
 
 
@@ -67,7 +67,7 @@ def test_quantize_rows(M, K, fmt):
     deq = got * dq.cpu()[:, None]
     sub = dq.cpu()[:, None] * (2.0 ** -10 if fmt == 0 else 2.0 ** -17)                  # half a subnormal step
     assert ((deq - x.float()).abs() <= half_ulp * x.float().abs() * 1.001 + sub).all(), "quantisation error above half an ulp"
-    assert (deq[M // 2] == 0).all() and dq[M // 2].item() == 1.0
+    assert (deq[M // 2] == 0).all() and dq[M // 2].item() == 0.0
 
 
 def _f8_operands(M, N, K, fmt_a, fmt_b, seed):
