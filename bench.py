@@ -31,6 +31,7 @@ PEAK_FP8_TFLOPS = 5000.0      # dense fp8 peak on v_mfma_f32_16x16x128_f8f6f4 (s
 ROOFLINE_KERNELS = {
     "gemm_nt": (PEAK_BF16_TFLOPS, "gemm_nt (gemm_nta_kernel<EPI, PRE, SCHED>: 4 waves x 512 registers, hand-scheduled v_mfma_f32_16x16x32_bf16 main loop, 256x256x64 tile, all epilogue instantiations; gemm_nt2_kernel on ragged shapes)"),
     "gemm_nt_f8": (PEAK_FP8_TFLOPS, "gemm_nt_f8 (gemm_f8a_kernel: 4 waves x 512 registers, hand-scheduled v_mfma_f32_16x16x128_f8f6f4 main loop, 256x256x128 tile; gemm_nt_f8_kernel on ragged shapes)"),
+    "gemm_tn_f8": (PEAK_FP8_TFLOPS, "gemm_tn_f8 (gemm_tn8_kernel: hand-scheduled fp8 weight-gradient GEMM, ds_read_b64_tr_b8 fragments, v_mfma_f32_16x16x128_f8f6f4, 256x256 tile, split-M)"),
     "gemm_tn": (PEAK_BF16_TFLOPS, "gemm_tn (gemm_tna_kernel: hand-scheduled bf16 weight-gradient GEMM, 256x256 tile, split-M; gemm_tn2 / gemm_tn3 on ragged shapes)"),
 }
 
@@ -117,6 +118,15 @@ KEEP_VALUE_MS_PER_GB = (("v", "h8", 1.5), ("t", "h8", 1.13), ("v", "a", 0.94), (
 # the bytes of "h8" for the same saved GEMM) ranks below qkv.
 KEEP_VALUE_MS_PER_GB_EXACT = (("v", "a", 0.94), ("v", "x1", 0.91), ("t", "x1", 0.88), ("v", "qkv", 0.79), ("v", "h", 0.75),
                               ("t", "a", 0.70), ("t", "qkv", 0.66), ("t", "h", 0.57))
+
+
+# The fp8 engine (round 6: per-tensor keep sets there too), priced on ViT-H/14 + text-77 at local batch 2048 (profiles/
+# r06_bench_h14_B2048_fp8_wgrad8_first.json): the attention output saves the attention forward (1.7 ms per GB), the e4m3
+# pre-activation LN2 + the c_fc GEMM (1.3), x1 the out-projection + a row quantiser (1.0), qkv LN1 + the in-projection (0.7).
+KEEP_VALUE_MS_PER_GB_FP8 = (("v", "a", 1.68), ("v", "h8", 1.33), ("t", "h8", 1.05), ("v", "x1", 1.02), ("t", "x1", 0.94),
+                            ("t", "a", 0.85), ("v", "qkv", 0.68), ("t", "qkv", 0.56))
+KEEP_VALUE_MS_PER_GB_FP8_EXACT = (("v", "a", 1.68), ("v", "x1", 1.02), ("t", "x1", 0.94), ("t", "a", 0.85), ("v", "qkv", 0.68),
+                                  ("v", "h", 0.66), ("t", "qkv", 0.56), ("t", "h", 0.52))
 
 
 def plan_keep_tensors(budget, layers, nbytes, order=KEEP_VALUE_MS_PER_GB, pruned_last=()):
@@ -384,9 +394,9 @@ def main():
     # Activation policy: every block recomputes in backward (the reference's --grad-checkpointing) except the
     # first `keep` blocks of each tower, which keep their GEMM / attention outputs in the HBM that is left over.
     # "auto" measures the peak of one all-recompute step and spends ~85 % of the remaining HBM.
-    # the upgraded tier: "light8" (MLP pre-activation kept as e4m3 bytes, 4 D bytes per token on top of the medium set) for
-    # the bf16 engines; the fp8 engine's GEMM has no such epilogue and keeps the bf16 pre-activation ("light", 8 D bytes)
-    use_l8 = args.precision != "fp8" and not args.no_light8
+    # the upgraded tier: "light8" (MLP pre-activation kept as e4m3 bytes, 4 D bytes per token on top of the medium set); since
+    # round 6 the fp8 GEMM has the epilogues for it too
+    use_l8 = not args.no_light8
 
     tensor_plan = None                 # bf16 engines under --keep-blocks auto: per-tensor counts (plan_keep_tensors)
 
@@ -434,11 +444,14 @@ def main():
         lv_b, lt_b = (vt.light8_keep_bytes(B // A * L_img), tt.light8_keep_bytes(B // A * args.ctx)) if use_l8 else \
             (vt.light_keep_bytes(B // A * L_img), tt.light_keep_bytes(B // A * args.ctx))
 
-        per_tensor = args.precision != "fp8" and not args.tier_plan
+        per_tensor = not args.tier_plan
         tok_v, tok_t = B // A * L_img, B // A * args.ctx
         tb = {(tw, n): tr.tensor_keep_bytes(tok, n) for tw, tr, tok in (("v", vt, tok_v), ("t", tt, tok_t)) for n in ("h8", "h", "a", "x1", "qkv")}
-        order = KEEP_VALUE_MS_PER_GB if use_l8 else KEEP_VALUE_MS_PER_GB_EXACT
-        if per_tensor:
+        if args.precision == "fp8":
+            order = KEEP_VALUE_MS_PER_GB_FP8 if use_l8 else KEEP_VALUE_MS_PER_GB_FP8_EXACT
+        else:
+            order = KEEP_VALUE_MS_PER_GB if use_l8 else KEEP_VALUE_MS_PER_GB_EXACT
+        if per_tensor and args.precision != "fp8":
             exact_plan_fn = lambda budget: plan_keep_tensors(budget, layers, tb, KEEP_VALUE_MS_PER_GB_EXACT, pruned_last)
 
         def plan(budget):

@@ -231,7 +231,13 @@ extern "C" int clipa_gemm_nt_f8(const void* A8, const void* B8, const float* sca
   if (K <= 0 || K % 16 != 0) { clipa_set_error("gemm_nt_f8: K=%ld must be a positive multiple of 16", (long)K); return CLIPA_ERR_ARG; }
   if (lda % 16 != 0 || ldb % 16 != 0) { clipa_set_error("gemm_nt_f8: lda, ldb must be multiples of 16 bytes"); return CLIPA_ERR_ARG; }
   if (N % 8 != 0 || ldc % 8 != 0) { clipa_set_error("gemm_nt_f8: N, ldc must be multiples of 8"); return CLIPA_ERR_ARG; }
-  if (epi < CLIPA_EPI_NONE || epi > CLIPA_EPI_DACT) { clipa_set_error("gemm_nt_f8: unknown epilogue %d", epi); return CLIPA_ERR_ARG; }
+  if (epi < CLIPA_EPI_NONE || epi > CLIPA_EPI_DACT8) { clipa_set_error("gemm_nt_f8: unknown epilogue %d", epi); return CLIPA_ERR_ARG; }
+  // e4m3 second output / operand (the "h8" kept tensor of the engine): epilogues of the four-wave kernel only
+  const int pre8 = epi == CLIPA_EPI_ACT_PRE8, aux8 = epi == CLIPA_EPI_DACT8;
+  if (pre8) epi = CLIPA_EPI_ACT;
+  if (aux8) epi = CLIPA_EPI_DACT;
+  if ((pre8 || aux8) && !f8a_eligible(M, N, K, fmt_b)) { clipa_set_error("gemm_nt_f8: CLIPA_EPI_ACT_PRE8 / CLIPA_EPI_DACT8 need whole-tile shapes (M, N %% 256 == 0, K %% 256 == 0, K >= 512, e4m3 weights)"); return CLIPA_ERR_ARG; }
+  if (pre8 && !C2) { clipa_set_error("gemm_nt_f8: CLIPA_EPI_ACT_PRE8 needs C2"); return CLIPA_ERR_ARG; }
   if ((epi == CLIPA_EPI_ADD || epi == CLIPA_EPI_DACT) && (!aux || ldaux % 8 != 0)) { clipa_set_error("gemm_nt_f8: epilogue %d needs aux with ldaux%%8==0", epi); return CLIPA_ERR_ARG; }
   if (C2 && epi != CLIPA_EPI_ACT) { clipa_set_error("gemm_nt_f8: C2 (pre-activation copy) goes with CLIPA_EPI_ACT only"); return CLIPA_ERR_ARG; }
   if ((fmt_a != 0 && fmt_a != 1) || (fmt_b != 0 && fmt_b != 1)) { clipa_set_error("gemm_nt_f8: formats are 0 (e4m3) or 1 (e5m2)"); return CLIPA_ERR_ARG; }
@@ -249,11 +255,11 @@ extern "C" int clipa_gemm_nt_f8(const void* A8, const void* B8, const float* sca
   hipStream_t st = (hipStream_t)stream;
   // whole-tile shapes with e4m3 weights (every block GEMM of the BASELINE configurations) run on the four-wave kernel with the
   // hand-scheduled main loop (gemm_f8a.hip); bit-identical outputs.  clipa_internal_debug_set(1, .) keeps them on this file's kernel.
-  if (g_nt_variant.load(std::memory_order_relaxed) != 1 && !(a.abl & 13) && f8a_eligible(M, N, K, fmt_b)) {
+  if (pre8 || aux8 || (g_nt_variant.load(std::memory_order_relaxed) != 1 && !(a.abl & 13) && f8a_eligible(M, N, K, fmt_b))) {
     F8AArgs b;
     b.A = a.A; b.B = a.B; b.C = a.C; b.C2 = a.C2; b.bias = a.bias; b.aux = a.aux; b.sa = a.sa; b.sb = a.sb;
     b.M = a.M; b.N = a.N; b.K = a.K; b.lda = a.lda; b.ldb = a.ldb; b.ldc = a.ldc; b.ldaux = a.ldaux;
-    b.alpha = a.alpha; b.epi = a.epi; b.act = a.act; b.abl = a.abl; b.gm = a.gm;
+    b.alpha = a.alpha; b.epi = a.epi; b.act = a.act; b.abl = a.abl; b.gm = a.gm; b.pre8 = pre8; b.aux8 = aux8;
     return f8a_launch(b, fmt_a, dev, num_cu, st);
   }
   g_last_gemm.store(7, std::memory_order_relaxed);

@@ -11,6 +11,7 @@ struct F8AArgs {
   long lda, ldb, ldc, ldaux;            // A, B: bytes; C, aux: elements
   float alpha;
   int epi, act, abl, gm;
+  int pre8, aux8;                       // C2 / aux hold e4m3 bytes (1 byte per element, row strides ldc / ldaux in BYTES): CLIPA_EPI_ACT_PRE8 / CLIPA_EPI_DACT8
 };
 
 bool f8a_eligible(long M, long N, long K, int fmt_b);

@@ -352,8 +352,9 @@ __global__ void rowscale_max_kernel(const float* __restrict__ a, const float* __
 
 __device__ __forceinline__ float inv_or_zero(float t) { return t > 0.f ? 1.0f / t : 0.f; }
 
-// ACT: -1 = none, else the MLP activation of common.h applied to x first
-template <int ACT>
+// ACT: -1 = none, else the MLP activation of common.h applied to x first.  IN8: x holds e4m3 bytes (the kept pre-activation
+// of the "h8" tier) instead of bf16
+template <int ACT, bool IN8>
 __global__ void scale_quantize_rows_kernel(const char* __restrict__ x, long ldx, const float* __restrict__ rowscale,
                                            const float* __restrict__ t_dev, char* __restrict__ q, long ldq, long rows, int nch) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -362,7 +363,8 @@ __global__ void scale_quantize_rows_kernel(const char* __restrict__ x, long ldx,
   const int ch = (int)(i - r * nch);
   const float s = rowscale[r] * inv_or_zero(t_dev[0]);
   float f[8];
-  unpack8(ld_stream<u32x4>(x + ((size_t)r * ldx + (size_t)ch * 8) * 2), f);
+  if (IN8) e4m3x8_to_f32(ld_stream<u32x2>(x + (size_t)r * ldx + (size_t)ch * 8), f);
+  else unpack8(ld_stream<u32x4>(x + ((size_t)r * ldx + (size_t)ch * 8) * 2), f);
   if (ACT >= 0) {
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
@@ -457,25 +459,37 @@ extern "C" int clipa_rowscale_max(const float* a, const float* b, int64_t n, flo
   return clipa_check_launch("rowscale_max");
 }
 
-extern "C" int clipa_scale_quantize_rows(const void* x, const float* rowscale, const float* t_dev, void* q, int64_t rows, int64_t K,
-                                         int64_t ldx, int64_t ldq, int act, void* stream) {
+namespace {
+template <bool IN8>
+int scale_quantize_launch(const char* what, const void* x, const float* rowscale, const float* t_dev, void* q, int64_t rows, int64_t K,
+                          int64_t ldx, int64_t ldq, int act, void* stream) {
   if (rows <= 0) return CLIPA_OK;
-  if (K <= 0 || K % 8 != 0) { clipa_set_error("scale_quantize_rows: K=%ld must be a positive multiple of 8", (long)K); return CLIPA_ERR_ARG; }
-  if (ldx % 8 != 0 || ldq % 8 != 0 || ldx < K || ldq < K) { clipa_set_error("scale_quantize_rows: ldx, ldq must be multiples of 8 and >= K"); return CLIPA_ERR_ARG; }
-  if (act < -1 || act > ACT_QUICK_GELU) { clipa_set_error("scale_quantize_rows: unknown activation %d", act); return CLIPA_ERR_ARG; }
-  if (!rowscale || !t_dev) { clipa_set_error("scale_quantize_rows: rowscale and t are required"); return CLIPA_ERR_ARG; }
+  if (K <= 0 || K % 8 != 0) { clipa_set_error("%s: K=%ld must be a positive multiple of 8", what, (long)K); return CLIPA_ERR_ARG; }
+  if (ldx % 8 != 0 || ldq % 8 != 0 || ldx < K || ldq < K) { clipa_set_error("%s: ldx, ldq must be multiples of 8 and >= K", what); return CLIPA_ERR_ARG; }
+  if (act < -1 || act > ACT_QUICK_GELU) { clipa_set_error("%s: unknown activation %d", what, act); return CLIPA_ERR_ARG; }
+  if (!rowscale || !t_dev) { clipa_set_error("%s: rowscale and t are required", what); return CLIPA_ERR_ARG; }
   const long nch = K / 8, total = rows * nch;
   const long blocks = (total + 255) / 256;
-  if (blocks > 0x7fffffffL) { clipa_set_error("scale_quantize_rows: too many elements"); return CLIPA_ERR_ARG; }
+  if (blocks > 0x7fffffffL) { clipa_set_error("%s: too many elements", what); return CLIPA_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)blocks), block(256);
-#define SQ_LAUNCH(A) hipLaunchKernelGGL((scale_quantize_rows_kernel<A>), grid, block, 0, st, (const char*)x, (long)ldx, rowscale, t_dev, (char*)q, (long)ldq, (long)rows, (int)nch)
+#define SQ_LAUNCH(A) hipLaunchKernelGGL((scale_quantize_rows_kernel<A, IN8>), grid, block, 0, st, (const char*)x, (long)ldx, rowscale, t_dev, (char*)q, (long)ldq, (long)rows, (int)nch)
   if (act < 0) SQ_LAUNCH(-1);
   else if (act == ACT_GELU_ERF) SQ_LAUNCH(ACT_GELU_ERF);
   else if (act == ACT_GELU_TANH) SQ_LAUNCH(ACT_GELU_TANH);
   else SQ_LAUNCH(ACT_QUICK_GELU);
 #undef SQ_LAUNCH
-  return clipa_check_launch("scale_quantize_rows");
+  return clipa_check_launch(what);
+}
+}  // namespace
+
+extern "C" int clipa_scale_quantize_rows(const void* x, const float* rowscale, const float* t_dev, void* q, int64_t rows, int64_t K,
+                                         int64_t ldx, int64_t ldq, int act, void* stream) {
+  return scale_quantize_launch<false>("scale_quantize_rows", x, rowscale, t_dev, q, rows, K, ldx, ldq, act, stream);
+}
+extern "C" int clipa_scale_quantize_rows_e4m3(const void* x8, const float* rowscale, const float* t_dev, void* q, int64_t rows,
+                                              int64_t K, int64_t ldx, int64_t ldq, int act, void* stream) {
+  return scale_quantize_launch<true>("scale_quantize_rows_e4m3", x8, rowscale, t_dev, q, rows, K, ldx, ldq, act, stream);
 }
 
 extern "C" int clipa_layernorm_fwd_q8s(const void* x, const float* gamma, const float* beta, const float* rowscale, const float* t_dev,

@@ -150,56 +150,74 @@ def _wgrad8(dq, ds, sx, emit, out_dtype, cfg):
     return ops.gemm_tn_f8(dq, emit(ds, t), t=t, fmt_p=cfg.get("fp8_grad_fmt", ops.FMT_E4M3), out_dtype=out_dtype)
 
 
+def _fp8_keep_set(keep):
+    """-> (kept tensor names | None, full): the named tiers of the bf16 engine and its per-tensor sets ("qkv", "a" = attention output +
+    statistics, "x1", "h" = bf16 pre-activation, "h8" = the same as saturating e4m3 bytes written by the c_fc epilogue) hold in fp8
+    mode too (round 6); True / "full" additionally keeps the LayerNorm outputs and the activation in bf16."""
+    if not keep:
+        return None, False
+    if keep is True or keep == "full":
+        return KEEP_SETS["light"], True
+    return KEEP_SETS.get(keep, keep), False
+
+
 def _block_forward_fp8(x, P, cfg, keep, need_y=True, scales=None):
     """_block_forward with the four linear layers on the fp8 MFMA path (BASELINE.json configs[3]): the LayerNorms emit the
     e4m3 operand of the GEMM that follows them, the attention output and the MLP activation are quantised per token by
     clipa_quantize_rows; everything between the GEMMs (residual stream, attention, softmax statistics, kept tensors) is
     bf16 exactly as in the bf16 engine.  -> (y, kept tensors | None, scales): scales = the per-token scales (s1, sa, s2, sg) of
     the four GEMM inputs (LN1 output, attention output, LN2 output, activation), a few MB that every block keeps - the fp8
-    weight gradients of the backward derive their tensor scale from them (_wgrad8).  need_y=False (the backward-time recompute)
-    produces the pre-activation only: the activation is re-materialised as an fp8 operand there, its scale comes in through `scales`."""
+    weight gradients of the backward derive their tensor scale from them (_wgrad8).  need_y=False: no output, only what the
+    backward reads (_fp8_fill on nothing)."""
     B, L, H, causal, act = cfg["B"], cfg["L"], cfg["H"], cfg["causal"], cfg["act"]
-    if keep == "light8":          # the e4m3 pre-activation copy is an epilogue of the bf16 GEMM only: plain light keep here
-        keep = "light"
-    if isinstance(keep, frozenset):   # per-tensor keep sets are a bf16-engine feature: the nearest named tier here
-        keep = "light" if ("h" in keep or "h8" in keep) else ("medium" if keep else False)
-    full = bool(keep) and keep not in ("light", "medium")
+    if not need_y:
+        return None, _fp8_fill(x, (None,) * 8, P, cfg), scales
+    ks, full = _fp8_keep_set(keep)
+    ks = ks or frozenset()
     h1, q1, s1 = ops.layernorm_fwd_q8(x, P["ln1_w"], P["ln1_b"], cfg["eps"], want_bf16=full)
     qkv = _lin8(q1, s1, P, "in")
     del q1
-    a, stats = _attn_fwd(qkv, cfg, bool(keep))
+    a, stats = _attn_fwd(qkv, cfg, "a" in ks)
     qa, sa = ops.quantize_rows(a)
     x1 = _lin8(qa, sa, P, "out", epi=ops.EPI_ADD, aux=x)
     del qa
     h2, q2, s2 = ops.layernorm_fwd_q8(x1, P["ln2_w"], P["ln2_b"], cfg["eps"], want_bf16=full)
-    y = g = hpre = sg = None
-    if need_y:
-        if keep and keep != "medium":
-            g, hpre = _lin8(q2, s2, P, "fc", epi=ops.EPI_ACT, act=act, want_pre=True)
-        else:
-            g = _lin8(q2, s2, P, "fc", epi=ops.EPI_ACT, act=act)
-        del q2
-        qg, sg = ops.quantize_rows(g)
-        y = _lin8(qg, sg, P, "proj", epi=ops.EPI_ADD, aux=x1)
-        del qg
+    want_pre = "e4m3" if "h8" in ks else ("h" in ks)
+    if want_pre:
+        g, hpre = _lin8(q2, s2, P, "fc", epi=ops.EPI_ACT, act=act, want_pre=want_pre)
     else:
-        hpre = _lin8(q2, s2, P, "fc")                  # bf16(LN2(x1) W^T + b): what the activation epilogue's second output holds
-        del q2
-        sg = scales[3] if scales is not None else ops.quantize_rows(ops.activation_fwd(hpre, act))[1]
+        g, hpre = _lin8(q2, s2, P, "fc", epi=ops.EPI_ACT, act=act), None
+    del q2
+    qg, sg = ops.quantize_rows(g)
+    y = _lin8(qg, sg, P, "proj", epi=ops.EPI_ADD, aux=x1)
+    del qg
     sc = (s1, sa, s2, sg)
-    if keep in ("light", "medium"):
-        return y, (None, qkv, a, stats, x1, None, hpre, None), sc
-    if keep:
-        return y, (h1, qkv, a, stats, x1, h2, hpre, g if full else None), sc
-    return y, None, sc
+    if not ks:
+        return y, None, sc
+    return y, (h1 if full else None, qkv if "qkv" in ks else None, a if "a" in ks else None, stats if "a" in ks else None,
+               x1 if "x1" in ks else None, h2 if full else None, hpre, g if full else None), sc
 
 
-def _fp8_fill_medium(kept, P, cfg):
-    """A "medium" fp8 block kept qkv / attention output / x1: LN2 + the c_fc GEMM again for the pre-activation (bit for bit the
-    forward's)."""
+def _fp8_fill(x, kept, P, cfg):
+    """Whatever an fp8 block did not keep of (qkv, attention output + statistics, x1, pre-activation), recomputed bit for bit
+    as the forward produced it.  The activation itself is never rebuilt in bf16: the weight gradient of c_proj re-materialises
+    it as an fp8 operand from the pre-activation (_block_backward_fp8), so a missing pre-activation costs LN2 + the c_fc GEMM
+    with a plain epilogue."""
     h1, qkv, a, stats, x1, h2, hpre, g = kept
-    _, q2, s2 = ops.layernorm_fwd_q8(x1, P["ln2_w"], P["ln2_b"], cfg["eps"], want_bf16=False)
-    hpre = _lin8(q2, s2, P, "fc")
+    if qkv is None:
+        _, q1, s1 = ops.layernorm_fwd_q8(x, P["ln1_w"], P["ln1_b"], cfg["eps"], want_bf16=False)
+        qkv = _lin8(q1, s1, P, "in")
+        del q1
+    if a is None:
+        a, stats = _attn_fwd(qkv, cfg, True)
+    if x1 is None:
+        qa, sa = ops.quantize_rows(a)
+        x1 = _lin8(qa, sa, P, "out", epi=ops.EPI_ADD, aux=x)
+        del qa
+    if hpre is None:
+        _, q2, s2 = ops.layernorm_fwd_q8(x1, P["ln2_w"], P["ln2_b"], cfg["eps"], want_bf16=False)
+        hpre = _lin8(q2, s2, P, "fc")          # bf16(LN2(x1) W^T + b): what the activation epilogue's second output holds
+        del q2
     return (h1, qkv, a, stats, x1, h2, hpre, g)
 
 
@@ -359,10 +377,7 @@ class ResBlockFn(torch.autograd.Function):
         ctx.inter = None
         if cfg.get("fp8"):
             scales, ctx.scales = ctx.scales, None
-            if box[0] is None or box[0][6] is None:     # nothing kept / no pre-activation ("medium"): recompute what is missing
-                kept = box[0]
-                box[0] = _block_forward_fp8(x, P, cfg, "light", need_y=False, scales=scales)[1] if kept is None else \
-                    _fp8_fill_medium(kept, P, cfg)
+            box[0] = _fp8_fill(x, box[0] if box[0] is not None else (None,) * 8, P, cfg)
             dx, grads = _block_backward_fp8(x, dy, box, P, cfg, scales)
         else:
             if box[0] is None:

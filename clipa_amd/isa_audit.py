@@ -65,13 +65,14 @@ def epilogue_store_counts(path, txt):
 
     def want(kname):
         """-> (16-byte stores, 8-byte stores) per epilogue copy.  gemm_nta_kernel<EPI, PRE (0 / 1 bf16 copy / 2 e4m3 copy), AUX8,
-        SCHED>, gemm_f8a_kernel<EPI, PRE (bool), FMT>."""
+        SCHED>, gemm_f8a_kernel<EPI, PRE (0 / 1 bf16 copy / 2 e4m3 copy), AUX8, FMT>."""
         m = re.search(r"gemm_nta_kernelILi(\d+)ELi(\d+)E", kname)
         if m:
             pre = int(m.group(2))
             return 32 * (2 if pre == 1 else 1), 32 if pre == 2 else 0
-        m = re.search(r"gemm_f8a_kernelILi(\d+)ELb([01])E", kname)
-        return 32 * (2 if m and m.group(2) == "1" else 1), 0
+        m = re.search(r"gemm_f8a_kernelILi(\d+)ELi(\d+)E", kname)
+        pre = int(m.group(2)) if m else 0
+        return 32 * (2 if pre == 1 else 1), 32 if pre == 2 else 0
 
     def close_kernel():
         if kernel is not None and copies == 0:

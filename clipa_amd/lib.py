@@ -63,6 +63,7 @@ SIGNATURES = {
     "clipa_quantize_rows_colsum": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _P, _I64, _P]),
     "clipa_rowscale_max": (_I32, [_P, _P, _I64, _P, _P]),
     "clipa_scale_quantize_rows": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _P]),
+    "clipa_scale_quantize_rows_e4m3": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _P]),
     "clipa_layernorm_fwd_q8s": (_I32, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P]),
     "clipa_gemm_tn_f8_workspace": (_I64, [_I64, _I64, _I64]),
     "clipa_gemm_tn_f8": (_I32, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _F, _P, _I32, _I32, _P, _I64, _P]),

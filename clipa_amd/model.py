@@ -154,7 +154,7 @@ class Transformer(nn.Module):
         # per token): no GEMM is re-run, gelu'(h) and the re-materialised activation come from the rounded value
         # (engine._block_forward).  Order of the tiers along the depth: light, light8, medium, recompute.
         self.light8_blocks = 0
-        # ... or tensor by tensor (bf16 engines; what bench.py's planner uses): the LAST keep_counts[t] blocks keep tensor t (their
+        # ... or tensor by tensor (what bench.py's planner uses; fp8 engines too since round 6): the LAST keep_counts[t] blocks keep tensor t (their
         # backward runs first, at the memory peak: the blocks that recompute do so after kept tensors have been released)
         # ("h8" e4m3 pre-activation - or "h", the same tensor in bf16: twice the bytes, bit-exact gradients -, "a" attention
         # output + statistics, "x1", "qkv"), on top of the named tiers above
@@ -180,7 +180,7 @@ class Transformer(nn.Module):
         light8 = dict(base, keep_this=True, keep="light8")
         n1, n2 = self.keep_blocks, self.keep_blocks + self.light8_blocks
         last = len(self.resblocks) - 1
-        counted = any(self.keep_counts.values()) and not self.fp8
+        counted = any(self.keep_counts.values())
         for i, blk in enumerate(self.resblocks):
             cfg = kept if i < n1 else (light8 if i < n2 else (medium if i < n2 + self.medium_blocks else base))
             if counted:

@@ -211,9 +211,25 @@ def layernorm_fwd_q8(x, gamma, beta, eps=1e-5, want_bf16=False):
     return y, q, dq
 
 
+def _whole_tiles_f8(M, N, K):
+    """Shapes the four-wave fp8 GEMM takes (gemm_f8a.hip: f8a_eligible): the fused e4m3 epilogues exist only there."""
+    return M % 256 == 0 and N % 256 == 0 and K % 256 == 0 and K >= 512
+
+
 def gemm_nt_f8(a8, sa, b8, sb, bias=None, *, epi=EPI_NONE, act=ACT_GELU_ERF, aux=None, alpha=1.0, want_pre=False,
                fmt_a=FMT_E4M3, fmt_b=FMT_E4M3):
-    """C[M,N] bf16 = epi(alpha * sa[m] * sb[n] * a8[M,K] @ b8[N,K]^T + bias); a8, b8 uint8 tensors of fp8 bytes."""
+    """C[M,N] bf16 = epi(alpha * sa[m] * sb[n] * a8[M,K] @ b8[N,K]^T + bias); a8, b8 uint8 tensors of fp8 bytes.
+    want_pre: True -> also the bf16 pre-activation; "e4m3" -> it as saturating e4m3 bytes (uint8 [M,N]: fused into the epilogue on
+    whole-tile shapes, GEMM + cast otherwise).  aux of EPI_DACT may be such a uint8 tensor."""
+    whole = _whole_tiles_f8(a8.shape[0], b8.shape[0], a8.shape[1]) and fmt_b == FMT_E4M3
+    if want_pre == "e4m3" and not (epi == EPI_ACT and whole):
+        o, pre = gemm_nt_f8(a8, sa, b8, sb, bias, epi=epi, act=act, aux=aux, alpha=alpha, want_pre=True, fmt_a=fmt_a, fmt_b=fmt_b)
+        return o, cast_e4m3(pre)
+    if aux is not None and aux.dtype == u8:
+        if epi != EPI_DACT:
+            raise RuntimeError("gemm_nt_f8: an e4m3 (uint8) second operand goes with EPI_DACT only")
+        if not whole:
+            aux = e4m3_to_bf16(aux)
     _chk(a8, u8, "a8", 2)
     _chk(b8, u8, "b8", 2)
     a8, lda = _rowmajor(a8)
@@ -229,14 +245,23 @@ def gemm_nt_f8(a8, sa, b8, sb, bias=None, *, epi=EPI_NONE, act=ACT_GELU_ERF, aux
                 raise RuntimeError(f"gemm_nt_f8: {name} must be a contiguous f32 vector of {n} elements")
     if bias is not None:
         _chk(bias, f32, "bias", 1)
+    pre8 = want_pre == "e4m3"
     out = torch.empty((M, N), device=a8.device, dtype=bf16)
-    pre = torch.empty((M, N), device=a8.device, dtype=bf16) if want_pre else None
-    ldaux = 0
-    if aux is not None:
+    pre = torch.empty((M, N), device=a8.device, dtype=u8 if pre8 else bf16) if want_pre else None
+    ldaux, aux_sz = 0, 2
+    if aux is not None and aux.dtype == u8:
+        _chk(aux, u8, "aux", 2)
+        aux, ldaux = _rowmajor(aux)
+        epi, aux_sz = EPI_DACT8, 1
+    elif aux is not None:
         _chk(aux, bf16, "aux", 2)
         aux, ldaux = _rowmajor(aux)
-    nbytes = 1.0 * (M * K + N * K) + 2.0 * M * N * (1 + (aux is not None) + bool(want_pre))
-    with _Timed("gemm_nt_f8", 2.0 * M * N * K, nbytes, f"{M},{N},{K},epi{epi}{'+pre' if want_pre else ''}"):
+    if pre8:
+        epi = EPI_ACT_PRE8
+    nbytes = 1.0 * (M * K + N * K) + 2.0 * M * N + (float(aux_sz) * M * N if aux is not None else 0) + \
+        ((1.0 if pre8 else 2.0) * M * N if want_pre else 0)
+    tag_epi = {EPI_ACT_PRE8: "1+pre8", EPI_DACT8: "3,aux8"}.get(epi, f"{epi}{'+pre' if want_pre else ''}")
+    with _Timed("gemm_nt_f8", 2.0 * M * N * K, nbytes, f"{M},{N},{K},epi{tag_epi}"):
         lib.call("clipa_gemm_nt_f8", _p(a8), _p(b8), _p(sa), _p(sb), _p(out), _p(pre), _p(bias), _p(aux), M, N, K, lda, ldb,
                  N, ldaux, float(alpha), epi, act, int(fmt_a), int(fmt_b), _stream())
     return (out, pre) if want_pre else out
@@ -257,8 +282,10 @@ def rowscale_max(a, b=None):
 
 
 def scale_quantize_rows(x, rowscale, t, act=-1):
-    """q[m,:] = e4m3(act(x[m,:]) * rowscale[m] / t[0]) - the activation operand of an fp8 weight gradient (act -1 = none)."""
-    _chk(x, bf16, "x", 2)
+    """q[m,:] = e4m3(act(x[m,:]) * rowscale[m] / t[0]) - the activation operand of an fp8 weight gradient (act -1 = none).
+    x bf16, or uint8 e4m3 bytes (the kept pre-activation of the "h8" tier)."""
+    in8 = x.dtype == u8
+    _chk(x, u8 if in8 else bf16, "x", 2)
     _chk(rowscale, f32, "rowscale", 1)
     _chk(t, f32, "t", 1)
     x, ld = _rowmajor(x)
@@ -266,8 +293,9 @@ def scale_quantize_rows(x, rowscale, t, act=-1):
     if rowscale.numel() != M:
         raise RuntimeError(f"scale_quantize_rows: {rowscale.numel()} row scales for {M} rows")
     q = torch.empty((M, K), device=x.device, dtype=u8)
-    with _Timed("scale_quantize_rows", 0.0, 3.0 * M * K, f"{M},{K},act{act}"):
-        lib.call("clipa_scale_quantize_rows", _p(x), _p(rowscale.contiguous()), _p(t), _p(q), M, K, ld, K, int(act), _stream())
+    with _Timed("scale_quantize_rows", 0.0, (2.0 if in8 else 3.0) * M * K, f"{M},{K},act{act}{',in8' if in8 else ''}"):
+        lib.call("clipa_scale_quantize_rows_e4m3" if in8 else "clipa_scale_quantize_rows", _p(x), _p(rowscale.contiguous()), _p(t),
+                 _p(q), M, K, ld, K, int(act), _stream())
     return q
 
 

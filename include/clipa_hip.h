@@ -75,7 +75,8 @@ int clipa_gemm_tn(const void* P, const void* Q, void* out, float* colsum_out, in
  * clipa_gemm_nt_f8: C = epi(alpha * scale_a[m] * scale_b[n] * A8 . B8^T + bias[n]) on v_mfma_f32_16x16x128_f8f6f4, fp32
  * accumulation, bf16 C / C2 / aux and the epilogues of clipa_gemm_nt; scale_a [M], scale_b [N] may be NULL (= 1).  Whole-tile
  * shapes (M, N % 256 == 0, K % 256 == 0, K >= 512, e4m3 weights) run on the four-wave kernel of gemm_f8a.hip, bit-identical.
- * K, lda, ldb % 16 == 0 (bytes); N, ldc, ldaux % 8 == 0.
+ * K, lda, ldb % 16 == 0 (bytes); N, ldc, ldaux % 8 == 0.  CLIPA_EPI_ACT_PRE8 / CLIPA_EPI_DACT8 (e4m3 pre-activation copy / operand, as in
+ * clipa_gemm_nt; round 6) exist on the four-wave kernel only: whole-tile shapes, else CLIPA_ERR_ARG (compose GEMM + cast).
  * clipa_layernorm_fwd_q8: LayerNorm of bf16 rows emitting the e4m3 operand of the next GEMM (q, dq as quantize_rows of
  * the bf16-rounded output) and, when y != NULL, the bf16 output itself. */
 int clipa_quantize_rows(const void* x, void* q, float* dq, int64_t rows, int64_t K, int64_t ldx, int64_t ldq, int fmt,
@@ -93,7 +94,8 @@ int clipa_layernorm_fwd_q8(const void* x, const float* gamma, const float* beta,
  * sx the activation's own row scale of the forward pass (|Q8| <= 448, nothing saturates), and dW = t * P8^T . Q8.
  * clipa_rowscale_max: out[0] = max_m a[m] * b[m] (b NULL = 1; a, b >= 0) - the scalar t, kept on the device.
  * clipa_scale_quantize_rows: q[m,:] = e4m3(act(x[m,:]) * rowscale[m] / t[0]) (act -1 = none, else the MLP activation applied and
- * rounded to bf16 first: the re-materialised gelu(h) of transformer.py:217-219); x bf16, t device scalar (0 -> zeros).
+ * rounded to bf16 first: the re-materialised gelu(h) of transformer.py:217-219); x bf16, t device scalar (0 -> zeros);
+ * clipa_scale_quantize_rows_e4m3: the same with x as saturating e4m3 bytes (the kept pre-activation of CLIPA_EPI_ACT_PRE8).
  * clipa_layernorm_fwd_q8s: the same for x -> LayerNorm(x) (transformer.py:19-34; bf16-rounded as clipa_layernorm_fwd writes it).
  * clipa_gemm_tn_f8: out[R,C] = alpha * alpha_dev[0] * sum_m P8[m,R] * Q8[m,C] on v_mfma_f32_16x16x128_f8f6f4, fp32 accumulation
  * in split-M slabs + a fixed-order reduce; fmt_p 0 = e4m3 / 1 = e5m2 gradient bytes, Q8 e4m3; alpha_dev may be NULL (= 1);
@@ -108,6 +110,8 @@ int clipa_quantize_rows_colsum(const void* x, void* q, float* dq, float* colsum,
 int clipa_rowscale_max(const float* a, const float* b, int64_t n, float* out, void* stream);
 int clipa_scale_quantize_rows(const void* x, const float* rowscale, const float* t_dev, void* q, int64_t rows, int64_t K,
                               int64_t ldx, int64_t ldq, int act, void* stream);
+int clipa_scale_quantize_rows_e4m3(const void* x8, const float* rowscale, const float* t_dev, void* q, int64_t rows, int64_t K,
+                                   int64_t ldx, int64_t ldq, int act, void* stream);
 int clipa_layernorm_fwd_q8s(const void* x, const float* gamma, const float* beta, const float* rowscale, const float* t_dev,
                             void* q, int64_t rows, int64_t D, float eps, void* stream);
 int64_t clipa_gemm_tn_f8_workspace(int64_t M, int64_t R, int64_t C);

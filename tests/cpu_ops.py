@@ -73,7 +73,7 @@ def rowscale_max(a, b=None):
 
 
 def scale_quantize_rows(x, rowscale, t, act=-1):
-    v = x.float()
+    v = _from_e4m3(x) if x.dtype == torch.uint8 else x.float()
     if act >= 0:
         v = _act(v, act).to(bf16).float()
     inv = torch.where(t > 0, 1.0 / t, torch.zeros_like(t))

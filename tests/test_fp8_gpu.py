@@ -437,3 +437,69 @@ def test_fp8_weight_gradient_recipe_is_close_to_bf16():
         cos = torch.nn.functional.cosine_similarity(dw.flatten(), ref.flatten(), dim=0).item()
         assert rel < (0.06 if fmt == 0 else 0.10) and cos > 0.995, (fmt, rel, cos)
         assert abs((dw - ref).mean().item()) < 1e-3 * ref.abs().mean().item() + 1e-9 or rel < 0.05
+
+
+def test_gemm_f8a_e4m3_preactivation_epilogues():
+    """CLIPA_EPI_ACT_PRE8 / CLIPA_EPI_DACT8 of the four-wave fp8 GEMM (round 6: the "h8" kept tensor in fp8 mode): the fused
+    e4m3 copy is the cast of the bf16 pre-activation, the activation output is untouched, and the GELU-backward epilogue reading
+    the bytes equals the one reading their bf16 decoding - all bit for bit; ragged shapes compose GEMM + cast."""
+    o = ops()
+    from clipa_amd import lib
+    for act in (0, 1, 2):
+        M, N, K = 512, 768, 512
+        qa, sa, qb, sb, _ = _f8_operands(M, N, K, 0, 0, seed=31 + act)
+        bias = rnd(N, seed=4, dtype=f32)
+        A, SA, B, SB, BIAS = qa.to(DEV), sa.to(DEV), qb.to(DEV), sb.to(DEV), bias.to(DEV)
+        g_ref, pre = o.gemm_nt_f8(A, SA, B, SB, BIAS, epi=o.EPI_ACT, act=act, want_pre=True)
+        g8, pre8 = o.gemm_nt_f8(A, SA, B, SB, BIAS, epi=o.EPI_ACT, act=act, want_pre="e4m3")
+        assert lib.last_gemm() == 6
+        assert pre8.dtype == torch.uint8 and torch.equal(g8, g_ref)
+        assert torch.equal(pre8, o.cast_e4m3(pre))
+        dy8, sdy = o.quantize_rows(rnd(M, K, seed=9).to(DEV))
+        w8, sw = o.quantize_rows(rnd(N, K, seed=10, scale=0.05).to(DEV))
+        d8 = o.gemm_nt_f8(dy8, sdy, w8, sw, epi=o.EPI_DACT, act=act, aux=pre8)
+        d16 = o.gemm_nt_f8(dy8, sdy, w8, sw, epi=o.EPI_DACT, act=act, aux=o.e4m3_to_bf16(pre8))
+        assert torch.equal(d8, d16)
+    # ragged: same values through GEMM + cast
+    qa, sa, qb, sb, _ = _f8_operands(300, 264, 272, 0, 0, seed=77)
+    A, SA, B, SB = qa.to(DEV), sa.to(DEV), qb.to(DEV), sb.to(DEV)
+    g_ref, pre = o.gemm_nt_f8(A, SA, B, SB, epi=o.EPI_ACT, want_pre=True)
+    g8, pre8 = o.gemm_nt_f8(A, SA, B, SB, epi=o.EPI_ACT, want_pre="e4m3")
+    assert torch.equal(g8, g_ref) and torch.equal(pre8, o.cast_e4m3(pre))
+    dy8, sdy = o.quantize_rows(rnd(300, 288, seed=9).to(DEV))
+    w8, sw = o.quantize_rows(rnd(272, 288, seed=10, scale=0.05).to(DEV))
+    pre8b = o.cast_e4m3(rnd(300, 272, seed=12).to(DEV))
+    assert torch.equal(o.gemm_nt_f8(dy8, sdy, w8, sw, epi=o.EPI_DACT, aux=pre8b),
+                       o.gemm_nt_f8(dy8, sdy, w8, sw, epi=o.EPI_DACT, aux=o.e4m3_to_bf16(pre8b)))
+
+
+@pytest.mark.parametrize("name", ["cls_erf", "gap_sincos_tanh"])
+def test_fp8_per_tensor_keep_sets(name):
+    """bench.py's planner keeps a block's tensors one by one in fp8 mode too (round 6): any subset of the exact tensors (qkv,
+    attention output, x1, bf16 pre-activation) reproduces the all-recompute step bit for bit; with the e4m3 pre-activation
+    forward and loss stay bit-identical and the gradients stay within the tier's tolerance of the recomputed step."""
+    g = load_golden(name)
+    m = _fp8_engine(g)
+    _, loss0 = _fp8_step(m, g)
+    ref = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    for counts in ({"qkv": 2, "a": 1, "x1": 0, "h": 0, "h8": 0}, {"qkv": 0, "a": 2, "x1": 2, "h": 1, "h8": 0},
+                   {"qkv": 1, "a": 0, "x1": 1, "h": 2, "h8": 0}):
+        for t in (m.visual.transformer, m.transformer):
+            t.keep_counts = dict(counts)
+        _, loss = _fp8_step(m, g)
+        assert float(loss) == float(loss0), counts
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                assert torch.equal(p.grad, ref[k]), (counts, k)
+    for t in (m.visual.transformer, m.transformer):
+        t.keep_counts = {"qkv": 1, "a": 2, "x1": 2, "h": 0, "h8": 2}
+    _, loss = _fp8_step(m, g)
+    assert float(loss) == float(loss0)
+    worst = 1.0
+    for k, p in m.named_parameters():
+        if p.grad is None or p.grad.numel() == 1 or float(ref[k].float().norm()) < 1e-7:
+            continue
+        a, b = p.grad.double().reshape(-1), ref[k].double().reshape(-1)
+        worst = min(worst, float(torch.dot(a, b) / (a.norm() * b.norm())))
+    print(f"[fp8 h8 tier, {name}] worst gradient cosine against the recomputed step {worst:.4f}")
+    assert worst > 0.99
