@@ -145,6 +145,24 @@ def plan_keep_tensors(budget, layers, nbytes, order=KEEP_VALUE_MS_PER_GB, pruned
     return plan
 
 
+def dist_reservation(world, local_batch, embed_dim, n_params, grad_bytes_per_param):
+    """What a rank leaves free for the exchanges of a `world`-rank step, itemised (bytes) - memory the collective-free trial step of
+    the planner never sees (explicit amounts instead of smaller fractions):
+      rccl_buffers       RCCL's own hipMalloc'ed channel / proxy buffers (outside torch's allocator, so invisible to its peak
+                         statistics): an estimate, 0.5 GiB + 0.35 GiB per peer (ring + tree connections of up to 32 channels x
+                         4 MiB per protocol); the 1-rank records measure 0.3 GiB
+      ddp_buckets        DistributedDataParallel's flat gradient buckets (one copy of every gradient)
+      gathered_features  the fused [W B, 2 E] bf16 gather buffer, its fp32 gradient and the reduce-scatter output (loss.py)
+      logits_workspace   the similarity / cross-entropy workspace at the gathered width (per-row statistics and bf16 dlogits
+                         [B, W B] of simce)"""
+    W = max(1, int(world))
+    gathered = W * local_batch * 2 * embed_dim
+    return {"rccl_buffers": int((0.5 + 0.35 * (W - 1)) * 2 ** 30) if W > 1 else 0,
+            "ddp_buckets": int(n_params * grad_bytes_per_param) if W > 1 else 0,
+            "gathered_features": int(gathered * (2 + 4) + local_batch * 2 * embed_dim * 4) if W > 1 else 0,
+            "logits_workspace": int(2 * local_batch * W * local_batch * 2 + 16 * local_batch * 4) if W > 1 else 0}
+
+
 def agree_budget(budget, device):
     """Every rank must keep the SAME blocks (identical collectives, identical step time; a rank that keeps more can run
     out of HBM alone): all ranks adopt the smallest activation budget any of them measured."""
@@ -351,7 +369,7 @@ def main():
             return None
         key = (tx.data_ptr(), tx.shape[0])
         if key not in lens_cache:
-            lens_cache[key] = (tx.argmax(-1) + 1).cpu()
+            lens_cache[key] = (tx.argmax(-1) + 1).cpu().tolist()      # a list: DDP moves tensor arguments of forward to the device
         return lens_cache[key]
 
     def step(images=images, texts=texts):
@@ -427,15 +445,22 @@ def main():
     pruned_last = tuple(tw for tw, on in (("v", image_pruned), ("t", text_pruned)) if on)
     warm = args.warmup
     total_mem = torch.cuda.get_device_properties(dev).total_memory
+    # several ranks: what the exchanges need on top of what the planner's collective-free trial step measures, reserved explicitly;
+    # the 1-rank pre-flight (CLIPA_BENCH_FORCE_DIST=1) reserves for the world size the run is a rehearsal of (default 8)
+    assume_world = int(os.environ.get("CLIPA_BENCH_ASSUME_WORLD", "8")) if (dist_on and world == 1) else world
+    n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    reserve = dist_reservation(assume_world if dist_on else 1, B, cfg["embed_dim"], n_params, 2 if args.precision != "amp_bf16" else 4)
+    reserve_total = sum(reserve.values())
     if args.keep_blocks == "auto":
         torch.cuda.reset_peak_memory_stats(dev)
         step()                                   # one extra untimed all-recompute step, only to measure its peak
         torch.cuda.synchronize()                 # (under DDP this peak already contains the reducer's buckets)
         peak = torch.cuda.max_memory_allocated(dev)
-        # several ranks: a little less than alone (RCCL's channel buffers and the gathered features grow with the world size;
-        # the trial below is collective-free), and the vote after the trial backs every rank off together if it was too much
-        frac = args.keep_fraction if args.keep_fraction is not None else (0.94 if dist_on else 0.97)
-        budget0 = int(frac * (total_mem - peak)) - (6 << 30)
+        # several ranks: the same fraction as alone less an explicit reservation for what the collective-free trial below never
+        # allocates (dist_reservation: RCCL's buffers, DDP's buckets, the gathered features and their gradient); the vote after
+        # the trial backs every rank off together if it was too much
+        frac = args.keep_fraction if args.keep_fraction is not None else 0.97
+        budget0 = int(frac * (total_mem - peak)) - (6 << 30) - reserve_total
         if dist_on:
             budget0 = agree_budget(budget0, dev)
         # Spend the budget where a byte saves the most step time: tensor by tensor for the bf16 engines (plan_keep_tensors), whole
@@ -519,8 +544,8 @@ def main():
             # allocator segment covers - goes to the planner too, less a margin; one more trial decides, and a plan that does not
             # fit is taken back (the first plan is re-run, so the allocator is in the state the timed region will find).
             free_dev, _ = torch.cuda.mem_get_info(dev)
-            sp_frac = args.second_pass_fraction if args.second_pass_fraction is not None else (0.4 if dist_on else 0.6)
-            extra = int(sp_frac * free_dev) - ((4 if dist_on else 2) << 30)
+            sp_frac = args.second_pass_fraction if args.second_pass_fraction is not None else 0.6
+            extra = int(sp_frac * free_dev) - (2 << 30) - reserve_total
             if dist_on:
                 extra = agree_budget(extra, dev)
             snapshot = lambda t4: (tuple(int(v) for v in t4), json.dumps(tensor_plan, sort_keys=True))
@@ -543,10 +568,35 @@ def main():
     set_keep(int(keep_v), int(keep_t), int(med_v), int(med_t))
     from clipa_amd import loss as loss_mod
 
+    pressure_backoffs = 0
+
+    def memory_pressure():
+        """Several ranks: a rank that runs out of memory INSIDE a collective leaves its peers waiting for ever, so the decision to
+        back off is taken between steps, by all ranks together: True if any rank's allocator had to give cached blocks back to the
+        driver during the warm-up (num_alloc_retries moved: the step before an OutOfMemoryError) or sees < 1.5 GiB of free HBM."""
+        st = torch.cuda.memory_stats(dev)
+        free_dev, _ = torch.cuda.mem_get_info(dev)
+        mine = torch.tensor([int(st.get("num_alloc_retries", 0)) - memory_pressure.seen, -int(free_dev)], device=dev, dtype=torch.int64)
+        memory_pressure.seen = int(st.get("num_alloc_retries", 0))
+        dist.all_reduce(mine, op=dist.ReduceOp.MAX)
+        return int(mine[0]) > 0 or -int(mine[1]) < (3 << 29)
+    memory_pressure.seen = int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0))
+
     def timed_region():
-        for _ in range(warm):
-            step()
-        fence()
+        nonlocal pressure_backoffs, final_budget, keep_v, keep_t, med_v, med_t
+        for attempt in range(3):
+            for _ in range(warm):
+                step()
+            fence()
+            if not (dist_on and warm > 0 and final_budget is not None and attempt < 2 and memory_pressure()):
+                break
+            # every rank takes the same smaller plan (the budgets were agreed, so are the 12 GiB steps) and warms up again
+            pressure_backoffs += 1
+            final_budget -= 12 << 30
+            keep_v, keep_t, med_v, med_t = plan(final_budget)
+            set_keep(int(keep_v), int(keep_t), int(med_v), int(med_t))
+            opt.zero_grad(set_to_none=True)
+            torch.cuda.empty_cache()
         if dist_on:
             loss_mod.wait_timing_start()
         ops.profile_start(detail=args.shapes)
@@ -633,10 +683,20 @@ def main():
     # tokens up to each caption's EOT (SURVEY 8d's caption lengths ~ N(20, 8): about a quarter of the 77 positions).  Never
     # part of `value`, which stays on the reference's schedule unless --unpad-text asks otherwise.
     unpad = None
-    # (single process only: toggling the knob changes the autograd graph, which DistributedDataParallel(static_graph=True) forbids)
-    if args.unpad_steps > 0 and not args.unpad_text and not dist_on:
+    # Several ranks: toggling the knob changes the autograd graph, which DistributedDataParallel(static_graph=True) records in its
+    # first iteration - so this region (the LAST one that steps the model: it runs after the input-pipeline region below) drops the
+    # wrapper and wraps the model again with the knob set, as a trainer would set it before its wrap.
+    def unpad_region():
+        nonlocal step_model
+        rewrapped = False
         model.unpad_text = True
         try:
+            if dist_on and args.optimizer == "adamw":
+                import gc
+                step_model = None
+                gc.collect()                                                     # the old reducer unhooks itself when it dies
+                step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], static_graph=True)
+                rewrapped = True
             step()                                                           # warm-up (allocator, index structures)
             fence()
             tu = time.perf_counter()
@@ -649,14 +709,16 @@ def main():
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)
                 eu = float(tm)
             lens = (texts.argmax(-1) + 1).float()
-            unpad = {"value": round(B * world * args.unpad_steps / eu, 2), "unit": "pairs/s", "ms_per_step": round(1e3 * eu / args.unpad_steps, 2),
-                     "steps": args.unpad_steps, "loss": round(float(loss_u), 4),
-                     "text_positions_processed": round(float(lens.sum()) / (B * args.ctx), 4),
-                     "note": "model.unpad_text = True: the causal text tower runs on the tokens up to each caption's EOT, packed; features, "
-                             "loss and gradients are those of the padded step (tests/test_model_gpu.py::test_unpadded_text_tower_changes_nothing)"}
+            res = {"value": round(B * world * args.unpad_steps / eu, 2), "unit": "pairs/s", "ms_per_step": round(1e3 * eu / args.unpad_steps, 2),
+                   "steps": args.unpad_steps, "loss": round(float(loss_u), 4),
+                   "text_positions_processed": round(float(lens.sum()) / (B * args.ctx), 4),
+                   "note": "model.unpad_text = True: the causal text tower runs on the tokens up to each caption's EOT, packed; features, "
+                           "loss and gradients are those of the padded step (tests/test_model_gpu.py::test_unpadded_text_tower_changes_nothing)"
+                           + ("; DistributedDataParallel wrapper rebuilt with the knob set" if rewrapped else "")}
         except (RuntimeError, torch.OutOfMemoryError) as e:
-            unpad = {"value": None, "error": str(e)[:200]}
+            res = {"value": None, "error": str(e)[:200]}
         model.unpad_text = False
+        return res
 
     # PCIe-inclusive rate (the reference's batch_time includes the H2D copy, train.py:187-189): the same step
     # fed from pinned host memory with staged uint8 NHWC images through DevicePrefetcher (copy stream, double buffered) +
@@ -696,7 +758,11 @@ def main():
         except (RuntimeError, torch.OutOfMemoryError) as e:                      # the headline line must survive
             h2d = {"value": None, "error": str(e)[:200]}
 
-    mine = {"rank": rank, "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
+    if args.unpad_steps > 0 and not args.unpad_text:
+        unpad = unpad_region()
+
+    mine = {"rank": rank, "reserved_for_exchanges_gb": {k: round(v / 2**30, 2) for k, v in reserve.items()},
+            "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
             "peak_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2**30, 1),
             "alloc_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)),
             "kernel_ms_per_step": round(sum(v["ms"] for k, v in prof.items() if "|" not in k) / args.steps, 2),
@@ -757,7 +823,7 @@ def main():
             "peak_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2**30, 1),
             "alloc_retries": retries_timed,
             "alloc_retries_incl_extra_regions": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)),
-            "keep_plan_backoffs": backoffs,
+            "keep_plan_backoffs": backoffs, "memory_pressure_backoffs": pressure_backoffs,
             "keep_plan_second_pass_gb": None if second_pass is None else round(second_pass / 2**30, 1),
             "total_hbm_gb": round(total_mem / 2**30, 1),
             # what the step spends outside this library's kernels (rank 0): at one rank host gaps + optimizer glue, with several

@@ -342,6 +342,16 @@ int current_device(int* dev);             // hipGetDevice with error reporting
 extern std::atomic<int> g_nt_variant;     // clipa_internal_debug_set: gemm_nt kernel selection (0 = per-shape default)
 extern std::atomic<int> g_abl;            // clipa_internal_debug_set: experiment flags
 extern std::atomic<int> g_last_gemm;      // clipa_internal_last_gemm: 1 gemm_nt2, 2 gemm_nta, 3 gemm_tn2, 4 gemm_tn3, 5 gemm_tna
+// clipa_internal_gemm_counts: launches per kernel family since the last reset (tests prove that a model-level step really
+// dispatched the production kernels): slots 1..9 = the families of g_last_gemm, 10 = gemm_nta<ACT, e4m3 pre-activation copy>,
+// 11 = gemm_nta<DACT, e4m3 operand>, 12 / 13 = the same two epilogues of gemm_f8a
+constexpr int GEMM_COUNT_SLOTS = 16;
+extern std::atomic<long> g_gemm_count[GEMM_COUNT_SLOTS];
+inline void note_gemm(int family, int extra = 0) {
+  g_last_gemm.store(family, std::memory_order_relaxed);
+  g_gemm_count[family].fetch_add(1, std::memory_order_relaxed);
+  if (extra) g_gemm_count[extra].fetch_add(1, std::memory_order_relaxed);
+}
 
 constexpr int MAX_DEVICES = 64;
 

@@ -262,7 +262,7 @@ extern "C" int clipa_gemm_nt_f8(const void* A8, const void* B8, const float* sca
     b.alpha = a.alpha; b.epi = a.epi; b.act = a.act; b.abl = a.abl; b.gm = a.gm; b.pre8 = pre8; b.aux8 = aux8;
     return f8a_launch(b, fmt_a, dev, num_cu, st);
   }
-  g_last_gemm.store(7, std::memory_order_relaxed);
+  note_gemm(7);
   const long tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   const dim3 grid((unsigned)(tiles < num_cu ? tiles : num_cu)), block(NTHREADS);
 #define LAUNCH_F8(E, P2)                                                                                                   \

@@ -14,7 +14,8 @@
 // The round-1 generations (one tile per workgroup, loader/storer wave roles, ping-pong main loops) are in the git
 // history only; the round-2 experiments (direct MFMA-fragment epilogue, two workgroups per CU, five-slot K-32 ring,
 // deferred stores: none beat this kernel by more than its run-to-run noise except on one epilogue) are in
-// tools/experiments/gemm_nt_round2.hip, outside the package and libclipa_hip.so; measurements in profiles/r02_gemm_epilogue_experiments.md.
+// the git history (tools/experiments/gemm_nt_round2.hip up to round 4: outside the package and libclipa_hip.so); measurements in
+// profiles/r02_gemm_epilogue_experiments.md.
 #include "gemm_common.h"
 #include "internal_hooks.h"
 #include <cstdlib>
@@ -309,6 +310,7 @@ int ensure_nt_attrs(int dev) {
 std::atomic<int> g_nt_variant{0};
 std::atomic<int> g_abl{0};
 std::atomic<int> g_last_gemm{0};
+std::atomic<long> g_gemm_count[GEMM_COUNT_SLOTS];
 
 int current_device(int* dev) {
   const hipError_t e = hipGetDevice(dev);
@@ -347,6 +349,13 @@ extern "C" int clipa_internal_debug_set(int gemm_nt_variant, int ablation_flags)
 
 extern "C" int clipa_internal_last_gemm(void) { return g_last_gemm.load(std::memory_order_relaxed); }
 extern "C" int clipa_internal_debug_flags(void) { return g_abl.load(std::memory_order_relaxed); }
+extern "C" int clipa_internal_gemm_counts(long* out, int n, int reset) {
+  for (int i = 0; i < n && i < GEMM_COUNT_SLOTS; ++i) {
+    if (out) out[i] = g_gemm_count[i].load(std::memory_order_relaxed);
+    if (reset) g_gemm_count[i].store(0, std::memory_order_relaxed);
+  }
+  return GEMM_COUNT_SLOTS;
+}
 
 extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, const float* bias,
                              const void* aux, int64_t M, int64_t N, int64_t K, int64_t lda,
@@ -381,7 +390,7 @@ extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, co
   // kernel with the hand-scheduled main loop (gemm_nta.hip); bit-identical outputs.  clipa_internal_debug_set(1, .) keeps them on
   // gemm_nt2, clipa_internal_debug_set(2 + s, .) selects generated schedule s (A/B harnesses)
   const int variant = g_nt_variant.load(std::memory_order_relaxed);
-  g_last_gemm.store(1, std::memory_order_relaxed);
+  note_gemm(1);
   if (variant != 1 && !(a.abl & 13 & 0xfffff) && nta_eligible(a, out_f32))
     return nta_launch(a, dev, num_cu, variant >= 2 ? variant - 2 : NTA_DEFAULT_SCHEDULE, st);
   if (pre8 || aux8) { clipa_set_error("gemm_nt: e4m3 pre-activation epilogues need whole 256 x 256 x 128 tiles (M=%ld N=%ld K=%ld)", (long)M, (long)N, (long)K); return CLIPA_ERR_ARG; }

@@ -500,7 +500,7 @@ extern "C" int clipa_gemm_tn(const void* P, const void* Q, void* out, float* col
   }
   if (!launched) {
     const dim3 grid = per_xcd ? dim3((unsigned)(tiles * S_plan), 1) : dim3((unsigned)tiles, (unsigned)S_plan);
-    g_last_gemm.store(use_v3 ? 4 : 3, std::memory_order_relaxed);
+    note_gemm(use_v3 ? 4 : 3);
     if (use_v3) hipLaunchKernelGGL(gemm_tn3_kernel, grid, dim3(NTHREADS), 2 * STAGE_BYTES, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(gemm_tn2_kernel, grid, dim3(NTHREADS), 2 * STAGE_BYTES, (hipStream_t)stream, a);
     if (int rc = clipa_check_launch("gemm_tn")) return rc;

@@ -318,7 +318,7 @@ extern "C" int clipa_gemm_tn_f8(const void* P8, const void* Q8, void* out, int64
     // experiment flags: bits 26..27 select the schedule (1 + value; 0 = default)
     const int sel = (abl >> 26) & 3;
     const int sched = sel ? sel - 1 : TN8_DEFAULT_SCHEDULE;
-    g_last_gemm.store(8, std::memory_order_relaxed);
+    note_gemm(8);
     if (fmt_p == 1) tn8_launch_fast<1>(a, grid, sched, st);
     else tn8_launch_fast<0>(a, grid, sched, st);
     if (int rc = clipa_check_launch("gemm_tn8")) return rc;
@@ -330,7 +330,7 @@ extern "C" int clipa_gemm_tn_f8(const void* P8, const void* Q8, void* out, int64
     a.slice_rows = (int)pl.gen_slice; a.nslices = 0; a.m_first = pl.fast_rows; a.abl = abl;
     const long blocks = ((R + 15) / 16) * ((C + 15) / 16);
     const dim3 grid((unsigned)((blocks + 3) / 4), (unsigned)pl.S_gen);
-    if (pl.S_fast == 0) g_last_gemm.store(9, std::memory_order_relaxed);
+    if (pl.S_fast == 0) note_gemm(9);
     if (fmt_p == 1) hipLaunchKernelGGL(gemm_tn8_generic_kernel<1>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(gemm_tn8_generic_kernel<0>, grid, dim3(256), 0, st, a);
     if (int rc = clipa_check_launch("gemm_tn8_generic")) return rc;

@@ -163,7 +163,7 @@ int tna_launch(const TNArgs& a, int dev, dim3 grid, int sched, hipStream_t st) {
     }
   });
   if (g_tna_rc[dev]) return g_tna_rc[dev];
-  g_last_gemm.store(5, std::memory_order_relaxed);
+  note_gemm(5);
   if (sched == 1) hipLaunchKernelGGL(gemm_tna_kernel<1>, grid, dim3(TNA_THREADS), TNA_LDS, st, a);
   else hipLaunchKernelGGL(gemm_tna_kernel<0>, grid, dim3(TNA_THREADS), TNA_LDS, st, a);
   return clipa_check_launch("gemm_tna");

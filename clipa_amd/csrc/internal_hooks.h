@@ -19,6 +19,10 @@ int clipa_internal_debug_flags(void);      /* the flags word, for launchers outs
 /* Which GEMM kernel family the calling process launched last: 0 none, 1 gemm_nt2, 2 gemm_nta, 3 gemm_tn2, 4 gemm_tn3,
  * 5 gemm_tna, 6 gemm_f8a, 7 gemm_nt_f8_kernel. */
 int clipa_internal_last_gemm(void);
+/* Launches per GEMM kernel family since the last reset: out[1..9] = the families above (8 gemm_tn8, 9 its byte-gather kernel alone),
+ * out[10] / out[11] = gemm_nta with the e4m3 pre-activation copy / operand epilogue, out[12] / out[13] = the same of gemm_f8a.
+ * Returns the number of slots; reset != 0 zeroes them after the read. */
+int clipa_internal_gemm_counts(long* out, int n, int reset);
 #ifdef __cplusplus
 }
 #endif

@@ -87,10 +87,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
         const int ch = lane + c * 64;
         if (ch < nchunks && (k == 0 || two)) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) { const float d = v[k][c][i] - mean[k]; ss[k] += d * d; }
+          for (int i = 0; i < 8; ++i) { const float d = v[k][c][i] - mean[k]; ss[k] = __builtin_fmaf(d, d, ss[k]); }
         }
       }
-    const float rstd[2] = {rsqrtf(wave_sum(ss[0]) * invD + eps), rsqrtf(wave_sum(ss[1]) * invD + eps)};
+    const float rstd[2] = {rsqrtf(__builtin_fmaf(wave_sum(ss[0]), invD, eps)), rsqrtf(__builtin_fmaf(wave_sum(ss[1]), invD, eps))};
 #pragma unroll
     for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
         if (ch < nchunks && (k == 0 || two)) {
           float o[8];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] = (v[k][c][i] - mean[k]) * rstd[k] * g[c][i] + bt[c][i];
+          for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf((v[k][c][i] - mean[k]) * rstd[k], g[c][i], bt[c][i]);
           st8<YF32>(y, (size_t)(k ? r2 : r) * D + (size_t)ch * 8, o);
         }
       }
@@ -118,10 +118,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
                                                      void* __restrict__ dx, float* __restrict__ part,
                                                      long rows, int D, float eps, int C,
                                                      const float* __restrict__ beta = nullptr, void* __restrict__ yout = nullptr) {
-  // Contraction is OFF in this kernel and every fused multiply-add is written out: which products hipcc fuses under
-  // -ffp-contract=fast depends on their use counts, which differ between the EMIT and the plain instantiation - and the two must
-  // return the same dx / dgamma / dbeta bit for bit (a block's gradients may not depend on which of its tensors were kept).
-#pragma clang fp contract(off)
+  // Every multiply-add of the statistics and of the outputs is WRITTEN as __builtin_fmaf, here and in ln_fwd_kernel (and in the
+  // LayerNorm + quantise kernels of quant.hip): which products hipcc contracts under -ffp-contract=fast depends on use counts that
+  // differ between instantiations (and `#pragma clang fp contract(off)` is ignored under that flag - ADVICE r5), while the EMIT,
+  // plain and forward kernels must agree bit for bit on rstd, y, dx, dgamma, dbeta (a block's gradients may not depend on which
+  // of its tensors were kept).  What is left to the compiler are single multiplications and additions.
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -161,10 +162,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
       const int ch = lane + c * 64;
       if (ch < nchunks) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const float t = v[c][i] - mean; ss += t * t; }   // (unfused, as ln_fwd_kernel compiles it: same rstd)
+        for (int i = 0; i < 8; ++i) { const float t = v[c][i] - mean; ss = __builtin_fmaf(t, t, ss); }   // (ln_fwd_kernel's expression: same rstd)
       }
     }
-    const float rstd = rsqrtf(wave_sum(ss) * invD + eps);
+    const float rstd = rsqrtf(__builtin_fmaf(wave_sum(ss), invD, eps));
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {

@@ -11,6 +11,9 @@
 #include "stream.h"
 #include "clipa_hip.h"
 
+#ifndef LN_Q8_PREFETCH
+#define LN_Q8_PREFETCH 1                          // A/B knob (tools/stream8_bench.py --lib)
+#endif
 #ifndef LN_Q8_BLOCK_CAP
 #define LN_Q8_BLOCK_CAP 8192                      // A/B knob (tools/stream_lib_ab.py)
 #endif
@@ -98,6 +101,19 @@ __global__ __launch_bounds__(256) void quantize_rows_colsum_kernel(const char* _
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
     for (int i = 0; i < 8; ++i) cs[c][i] = 0.f;
+  // The next row's loads are issued before this row's arithmetic (two rows in flight per wave, as the LayerNorm + quantise
+  // kernels) where that fits the register file: hipcc needs 206 / 254 / 290 registers for the 6 / 8 / 16-chunk instantiations
+  // with the second row (two waves per SIMD: 3.5 TB/s at K = 3840 instead of 5.4), 98 and 183 for 4 and 10 chunks.
+  constexpr bool PF = NCH <= 4 || NCH == 10;
+  u32x4 nxt[PF ? NCH : 1];
+  if constexpr (PF) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + c * 64;
+      nxt[c] = u32x4{0, 0, 0, 0};
+      if (ch < nchunks && wid < rows) nxt[c] = ld_stream<u32x4>(x + ((size_t)wid * ldx + (size_t)ch * 8) * 2);
+    }
+  }
   for (long row = wid; row < rows; row += nw) {
     u32x4 v[NCH];
     float amax = 0.f;
@@ -105,8 +121,10 @@ __global__ __launch_bounds__(256) void quantize_rows_colsum_kernel(const char* _
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + c * 64;
       v[c] = u32x4{0, 0, 0, 0};
+      if constexpr (PF) v[c] = nxt[c];
       if (ch < nchunks) {
-        v[c] = ld_stream<u32x4>(x + ((size_t)row * ldx + (size_t)ch * 8) * 2);
+        if constexpr (PF) { if (row + nw < rows) nxt[c] = ld_stream<u32x4>(x + ((size_t)(row + nw) * ldx + (size_t)ch * 8) * 2); }
+        else v[c] = ld_stream<u32x4>(x + ((size_t)row * ldx + (size_t)ch * 8) * 2);
         float f[8];
         unpack8(v[c], f);
 #pragma unroll
@@ -183,18 +201,27 @@ __global__ __launch_bounds__(256) void ln_fwd_q8_kernel(const char* __restrict__
     }
   }
   const float invD = 1.0f / (float)D;
+  // the next row's loads are issued before this row's arithmetic (LN_Q8_PREFETCH: a wave keeps two rows in flight - these
+  // kernels are latency-bound at one row per wave and ~100 registers, tools/stream8_bench.py)
+  u32x4 nxt[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int ch = lane + c * 64;
+    nxt[c] = u32x4{0, 0, 0, 0};
+    if (ch < nchunks && wid < rows) nxt[c] = ld_stream<u32x4>(x + ((size_t)wid * D + (size_t)ch * 8) * 2);
+  }
   for (long r = wid; r < rows; r += nw) {
     float v[NCH][8];
     float sum = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + c * 64;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[c][i] = 0.f;
+      if (!LN_Q8_PREFETCH && ch < nchunks && r != wid) nxt[c] = ld_stream<u32x4>(x + ((size_t)r * D + (size_t)ch * 8) * 2);
+      unpack8(nxt[c], v[c]);
       if (ch < nchunks) {
-        unpack8(ld_stream<u32x4>(x + ((size_t)r * D + (size_t)ch * 8) * 2), v[c]);
 #pragma unroll
         for (int i = 0; i < 8; ++i) sum += v[c][i];
+        if (LN_Q8_PREFETCH && r + nw < rows) nxt[c] = ld_stream<u32x4>(x + ((size_t)(r + nw) * D + (size_t)ch * 8) * 2);
       }
     }
     const float mean = wave_sum(sum) * invD;
@@ -204,10 +231,10 @@ __global__ __launch_bounds__(256) void ln_fwd_q8_kernel(const char* __restrict__
       const int ch = lane + c * 64;
       if (ch < nchunks) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const float d = v[c][i] - mean; ss += d * d; }
+        for (int i = 0; i < 8; ++i) { const float d = v[c][i] - mean; ss = __builtin_fmaf(d, d, ss); }
       }
     }
-    const float rstd = rsqrtf(wave_sum(ss) * invD + eps);
+    const float rstd = rsqrtf(__builtin_fmaf(wave_sum(ss), invD, eps));      // (layernorm.hip: the expressions of ln_fwd_kernel, fused multiply-adds written out)
     float amax = 0.f;
     u32x4 yb[NCH];
 #pragma unroll
@@ -217,7 +244,7 @@ __global__ __launch_bounds__(256) void ln_fwd_q8_kernel(const char* __restrict__
       if (ch < nchunks) {
         float o[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = (v[c][i] - mean) * rstd * g[c][i] + bt[c][i];
+        for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf((v[c][i] - mean) * rstd, g[c][i], bt[c][i]);
         yb[c] = pack8(o);                       // the bf16 rounding of the plain LayerNorm kernel: q is derived from it
         if (y) st_stream<u32x4>(y + ((size_t)r * D + (size_t)ch * 8) * 2, yb[c]);
         unpack8(yb[c], o);
@@ -268,7 +295,7 @@ extern "C" int clipa_quantize_rows(const void* x, void* q, float* dq, int64_t ro
 }
 
 #ifndef QUANT_COLSUM_BLOCKS
-#define QUANT_COLSUM_BLOCKS 4096                  // persistent blocks of quantize_rows_colsum (A/B knob)
+#define QUANT_COLSUM_BLOCKS 2048                  // persistent blocks of quantize_rows_colsum (A/B: profiles/r06_stream_kernels_fp8_step_h14.jsonl)
 #endif
 namespace {
 long quant_colsum_blocks(long rows) {
@@ -405,18 +432,25 @@ __global__ __launch_bounds__(256) void ln_fwd_q8s_kernel(const char* __restrict_
   }
   const float invD = 1.0f / (float)D;
   const float it = inv_or_zero(t_dev[0]);
+  u32x4 nxt[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int ch = lane + c * 64;
+    nxt[c] = u32x4{0, 0, 0, 0};
+    if (ch < nchunks && wid < rows) nxt[c] = ld_stream<u32x4>(x + ((size_t)wid * D + (size_t)ch * 8) * 2);
+  }
   for (long r = wid; r < rows; r += nw) {
     float v[NCH][8];
     float sum = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + c * 64;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[c][i] = 0.f;
+      if (!LN_Q8_PREFETCH && ch < nchunks && r != wid) nxt[c] = ld_stream<u32x4>(x + ((size_t)r * D + (size_t)ch * 8) * 2);
+      unpack8(nxt[c], v[c]);
       if (ch < nchunks) {
-        unpack8(ld_stream<u32x4>(x + ((size_t)r * D + (size_t)ch * 8) * 2), v[c]);
 #pragma unroll
         for (int i = 0; i < 8; ++i) sum += v[c][i];
+        if (LN_Q8_PREFETCH && r + nw < rows) nxt[c] = ld_stream<u32x4>(x + ((size_t)(r + nw) * D + (size_t)ch * 8) * 2);
       }
     }
     const float mean = wave_sum(sum) * invD;
@@ -426,10 +460,10 @@ __global__ __launch_bounds__(256) void ln_fwd_q8s_kernel(const char* __restrict_
       const int ch = lane + c * 64;
       if (ch < nchunks) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const float d = v[c][i] - mean; ss += d * d; }
+        for (int i = 0; i < 8; ++i) { const float d = v[c][i] - mean; ss = __builtin_fmaf(d, d, ss); }
       }
     }
-    const float rstd = rsqrtf(wave_sum(ss) * invD + eps);
+    const float rstd = rsqrtf(__builtin_fmaf(wave_sum(ss), invD, eps));      // (layernorm.hip: the expressions of ln_fwd_kernel, fused multiply-adds written out)
     const float s = rowscale[r] * it;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -437,7 +471,7 @@ __global__ __launch_bounds__(256) void ln_fwd_q8s_kernel(const char* __restrict_
       if (ch < nchunks) {
         float o[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = (v[c][i] - mean) * rstd * g[c][i] + bt[c][i];
+        for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf((v[c][i] - mean) * rstd, g[c][i], bt[c][i]);
         unpack8(pack8(o), o);                   // the bf16 rounding of the LayerNorm output the forward GEMM saw
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] *= s;
@@ -460,6 +494,51 @@ extern "C" int clipa_rowscale_max(const float* a, const float* b, int64_t n, flo
 }
 
 namespace {
+// The e4m3-input activation variant through a table: an e4m3 byte has 256 values, so bf16(act(x)) is a 256-entry table in
+// LDS (1 KiB, built once per block by its 256 threads) and an element costs one LDS gather, a multiply and its share of a
+// conversion instead of ~14 VALU instructions of polynomial and rounding - the arithmetic version runs at 3.1 TB/s of its 2 bytes
+// per element (VALU-bound), the table version at the memory system's rate.  Same values bit for bit (the table holds what the
+// arithmetic kernel computes per element).  16 elements per thread (16-byte accesses), ROWS rows per block.
+template <int ACT, int ROWS>
+__global__ __launch_bounds__(256) void scale_quantize_rows_lut_kernel(const char* __restrict__ x, long ldx, const float* __restrict__ rowscale,
+                                                                      const float* __restrict__ t_dev, char* __restrict__ q, long ldq,
+                                                                      long rows, int nch16) {
+  __shared__ float lut[256];
+  {
+    float f[8];
+    u32x2 code;
+    code[0] = threadIdx.x;        // byte 0 of the first word = this thread's e4m3 code
+    code[1] = 0u;
+    e4m3x8_to_f32(code, f);
+    const f32x2 v = {f[0], f[0]};
+    const f32x2 a = act_fwd2<ACT>(v);
+    lut[threadIdx.x] = bf2f(f2bf(a.x));
+  }
+  __syncthreads();
+  const float it = inv_or_zero(t_dev[0]);
+  const long r0 = (long)blockIdx.x * ROWS;
+#pragma unroll
+  for (int rr = 0; rr < ROWS; ++rr) {
+    const long r = r0 + rr;
+    if (r >= rows) break;
+    const float s = rowscale[r] * it;
+    for (int ch = threadIdx.x; ch < nch16; ch += 256) {
+      const u32x4 in = ld_stream<u32x4>(x + (size_t)r * ldx + (size_t)ch * 16);
+      u32x4 out;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const unsigned c = in[w];
+        const float f0 = lut[c & 255u] * s, f1 = lut[(c >> 8) & 255u] * s, f2 = lut[(c >> 16) & 255u] * s, f3 = lut[c >> 24] * s;
+        int o = 0;
+        o = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(f0, -448.f, 448.f), __builtin_amdgcn_fmed3f(f1, -448.f, 448.f), o, false);
+        o = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(f2, -448.f, 448.f), __builtin_amdgcn_fmed3f(f3, -448.f, 448.f), o, true);
+        out[w] = (unsigned)o;
+      }
+      st_stream<u32x4>(q + (size_t)r * ldq + (size_t)ch * 16, out);
+    }
+  }
+}
+
 template <bool IN8>
 int scale_quantize_launch(const char* what, const void* x, const float* rowscale, const float* t_dev, void* q, int64_t rows, int64_t K,
                           int64_t ldx, int64_t ldq, int act, void* stream) {
@@ -472,6 +551,18 @@ int scale_quantize_launch(const char* what, const void* x, const float* rowscale
   const long blocks = (total + 255) / 256;
   if (blocks > 0x7fffffffL) { clipa_set_error("%s: too many elements", what); return CLIPA_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
+#ifndef SQ_LUT
+#define SQ_LUT 1                                   // A/B knob: 0 keeps the arithmetic kernel for e4m3 inputs
+#endif
+  if (IN8 && SQ_LUT && act >= 0 && K % 16 == 0 && ldx % 16 == 0 && ldq % 16 == 0 && (((size_t)x | (size_t)q) & 15) == 0 && (rows + 3) / 4 <= 0x7fffffffL) {
+    const dim3 g4((unsigned)((rows + 3) / 4)), b4(256);
+#define SQ_LUT_LAUNCH(A) hipLaunchKernelGGL((scale_quantize_rows_lut_kernel<A, 4>), g4, b4, 0, st, (const char*)x, (long)ldx, rowscale, t_dev, (char*)q, (long)ldq, (long)rows, (int)(K / 16))
+    if (act == ACT_GELU_ERF) SQ_LUT_LAUNCH(ACT_GELU_ERF);
+    else if (act == ACT_GELU_TANH) SQ_LUT_LAUNCH(ACT_GELU_TANH);
+    else SQ_LUT_LAUNCH(ACT_QUICK_GELU);
+#undef SQ_LUT_LAUNCH
+    return clipa_check_launch(what);
+  }
   const dim3 grid((unsigned)blocks), block(256);
 #define SQ_LAUNCH(A) hipLaunchKernelGGL((scale_quantize_rows_kernel<A, IN8>), grid, block, 0, st, (const char*)x, (long)ldx, rowscale, t_dev, (char*)q, (long)ldq, (long)rows, (int)nch)
   if (act < 0) SQ_LAUNCH(-1);

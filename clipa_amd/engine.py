@@ -329,7 +329,7 @@ BLOCK_PARAM_ORDER = ("ln1_w", "ln1_b", "w_in", "b_in", "w_out", "b_out", "ln2_w"
                      "b_proj")
 
 
-def _block_operands(params, cache, fp8=False):
+def _block_operands(params, cache, fp8=False, fp8_names=("in", "out", "fc", "proj")):
     ln1_w, ln1_b, w_in, b_in, w_out, b_out, ln2_w, ln2_b, w_fc, b_fc, w_proj, b_proj = params
     P = {
         "ln1_w": cache.f32(ln1_w), "ln1_b": cache.f32(ln1_b), "ln2_w": cache.f32(ln2_w), "ln2_b": cache.f32(ln2_b),
@@ -338,8 +338,11 @@ def _block_operands(params, cache, fp8=False):
         "b_in": cache.f32(b_in), "b_out": cache.f32(b_out), "b_fc": cache.f32(b_fc), "b_proj": cache.f32(b_proj),
         "dt_w_in": w_in.dtype, "dt_w_out": w_out.dtype, "dt_w_fc": w_fc.dtype, "dt_w_proj": w_proj.dtype,
     }
-    if fp8:   # e4m3 copies, one scale per output channel of the GEMM they feed (rows of W forward, rows of W^T backward)
+    if fp8:   # e4m3 copies, one scale per output channel of the GEMM they feed (rows of W forward, rows of W^T backward); only
+        # of the layers that run on the fp8 path (LastBlockFn: the in-projection alone - its B pooled rows take the bf16 GEMMs)
         for name, w in (("in", w_in), ("out", w_out), ("fc", w_fc), ("proj", w_proj)):
+            if name not in fp8_names:
+                continue
             P["w8_" + name] = cache.custom(w, "w8", lambda t, w=w: ops.quantize_rows(cache.w(w)))
             P["wt8_" + name] = cache.custom(w, "wt8", lambda t, w=w: ops.quantize_rows(cache.wt(w)))
     return P
@@ -403,7 +406,7 @@ class LastBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, rows, cfg, cache, *params):
-        P = _block_operands(params, cache, bool(cfg.get("fp8")))
+        P = _block_operands(params, cache, bool(cfg.get("fp8")), fp8_names=("in",))
         needs_grad = any(ctx.needs_input_grad)
         # token-level tensors this block keeps: the block's keep set like any other block's ("qkv", "a" = attention output +
         # softmax statistics; the named tiers all hold both); x1 / the pre-activation exist for the B pooled rows only
@@ -447,7 +450,7 @@ class LastBlockFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, rows = ctx.saved_tensors
         cfg, params = ctx.cfg, ctx.params
-        P = _block_operands(params, ctx.cache, bool(cfg.get("fp8")))
+        P = _block_operands(params, ctx.cache, bool(cfg.get("fp8")), fp8_names=("in",))
         a_c, x1, h2, hpre, g = ctx.small
         ctx.small = None
         dy = dy.contiguous()

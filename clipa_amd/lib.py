@@ -124,6 +124,16 @@ def last_gemm():
     return int(fn())
 
 
+def gemm_counts(reset=False):
+    """Launches per GEMM kernel family since the last reset (csrc/internal_hooks.h; tests only): list indexed like last_gemm(),
+    [10] / [11] gemm_nta with the e4m3 pre-activation copy / operand epilogue, [12] / [13] the same of gemm_f8a."""
+    fn = load().clipa_internal_gemm_counts
+    fn.restype, fn.argtypes = _I32, [ctypes.POINTER(ctypes.c_long), _I32, _I32]
+    buf = (ctypes.c_long * 16)()
+    fn(buf, 16, 1 if reset else 0)
+    return list(buf)
+
+
 def last_error():
     return load().clipa_last_error().decode("utf-8", "replace")
 

@@ -14,6 +14,8 @@ from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Optional, Tuple, Union
 
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -345,7 +347,7 @@ class CLIP(nn.Module):
         self._gather_partner = None          # weakref to a ClipLoss that opted in with loss.bind(model)
         # engine knob: run the causal text tower on the tokens up to each caption's EOT only.  Set it BEFORE the first iteration
         # under DistributedDataParallel(static_graph=True) (it changes the autograd graph); pass the caption lengths from the
-        # loader (`forward(image, text, text_lengths=...)`, a CPU tensor) to avoid a device-to-host read per step
+        # loader (`forward(image, text, text_lengths=...)`, a list / numpy array of text.argmax(-1) + 1) to avoid a device-to-host read per step
         self.unpad_text = False
         self.visual = VisionTransformer(
             image_size=vision_cfg.image_size, patch_size=vision_cfg.patch_size, width=vision_cfg.width,
@@ -410,17 +412,34 @@ class CLIP(nn.Module):
 
     def _text_varlen(self, text, text_lengths=None):
         """The index structure of the unpadded text tower (engine knob `unpad_text`), or None.  It needs the caption lengths on
-        the host (B integers).  `text_lengths` (CPU integer tensor [B], position of the EOT token + 1 - the loader has the token
-        ids on the host anyway) costs nothing; without it the lengths are read back from the device, a blocking copy on the
+the host (B integers).  `text_lengths` ([B] integers as a list / tuple / numpy array / CPU tensor: `text.argmax(-1) + 1`, the
+        position of the EOT token - the LARGEST id, model.py:251-254 - plus one; the loader has the token ids on the host anyway;
+        under DistributedDataParallel NOT a tensor, DDP would move it to the device; CLIPA_CHECK_TEXT_LENGTHS=1 verifies the
+        contract against the device's argmax) costs nothing; without it the lengths are read back from the device, a blocking copy on the
         compute stream: the host then waits until everything enqueued so far (the previous step's backward and optimizer) has
         drained and loses its launch run-ahead once per step - `forward` at least asks before the image tower is
         enqueued."""
         if not (self.unpad_text and self.causal and self.pool_style == 'open_clip'):
             return None
         if text_lengths is not None:
+            if torch.is_tensor(text_lengths) and text_lengths.device.type != "cpu":
+                # DistributedDataParallel(device_ids=[...]) moves every TENSOR argument of forward to the device (its _pre_forward
+                # runs _to_kwargs), so a CPU lengths tensor arrives here as a device tensor and `.cpu()` below would be exactly the
+                # blocking copy the argument exists to avoid (ADVICE r5): pass a list / tuple / numpy array, which DDP leaves alone
+                import warnings
+                warnings.warn("clipa_amd.CLIP: text_lengths arrived as a device tensor (under DistributedDataParallel pass a list, "
+                              "tuple or numpy array: DDP moves tensor arguments to the GPU) - reading it back blocks the host",
+                              RuntimeWarning, stacklevel=3)
             lens = torch.as_tensor(text_lengths).to(torch.int64).cpu()
             if lens.shape != (text.shape[0],) or int(lens.min()) < 1 or int(lens.max()) > text.shape[1]:
                 raise RuntimeError(f"text_lengths must be [B] integers in [1, {text.shape[1]}]")
+            if os.environ.get("CLIPA_CHECK_TEXT_LENGTHS") == "1":
+                # the contract: text_lengths[b] == text[b].argmax() + 1 (the reference pools x[arange, text.argmax(-1)],
+                # model.py:251-254); lengths derived otherwise (first EOT, attention mask) move the pooled row silently
+                want = ops.argmax_tokens(text.long()).to(torch.int64).cpu() + 1
+                if not torch.equal(want, lens):
+                    bad = int((want != lens).sum())
+                    raise RuntimeError(f"text_lengths disagrees with text.argmax(-1) + 1 on {bad} of {lens.numel()} captions")
             return ops.VarLen(lens, text.shape[1], text.device)
         eot = ops.argmax_tokens(text.long())
         return ops.VarLen(eot.to(torch.int64).cpu() + 1, text.shape[1], text.device)

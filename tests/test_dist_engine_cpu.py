@@ -44,7 +44,7 @@ def _worker(rank, world, port, q, unpad=False):
     ddp = torch.nn.parallel.DistributedDataParallel(m, static_graph=True)
     B = g.images_u8.shape[0] // world
     img, txt = g.images_u8[rank * B:(rank + 1) * B], g.texts[rank * B:(rank + 1) * B]
-    lens = (txt.argmax(-1) + 1) if unpad else None      # from the loader's host-side token ids: no device read-back
+    lens = (txt.argmax(-1) + 1).tolist() if unpad else None      # from the loader's host-side token ids, as a LIST: DDP moves tensor kwargs to the device
     loss_fn = clipa_amd.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True, rank=rank, world_size=world).bind(ddp)
     losses, hits = [], []
     for _ in range(4):

@@ -53,7 +53,7 @@ def _accum_step(ddp, loss_fn, img, txt, accum, lens=None):
     """training/train.py:216-256 restated: no-grad forward of every micro-batch caching the features, then per
     micro-batch a forward WITH grad whose features are spliced into the cached list, the full loss, backward."""
     feats = {"image_features": [], "text_features": []}
-    lens = lens.chunk(accum) if lens is not None else [None] * accum
+    lens = [c.tolist() for c in torch.as_tensor(lens).chunk(accum)] if lens is not None else [None] * accum      # lists: DDP leaves them on the host
     chunks = list(zip(img.chunk(accum), txt.chunk(accum), lens))
     with torch.no_grad():
         for im, tx, ln in chunks:
@@ -89,7 +89,7 @@ def _worker(rank, world, port, q, accum=1, unpad=False):
     txt = txt[rank * B_LOC:(rank + 1) * B_LOC]
     # the caption lengths come from the host side of the loader (no device read-back): the ranks' packed text matrices have
     # different row counts - the towers are rank-local, no collective sees them
-    lens = (txt.argmax(-1) + 1) if unpad else None
+    lens = (txt.argmax(-1) + 1).cpu().tolist() if unpad else None      # host-side list (a tensor kwarg would be moved to the GPU by DDP)
     txt = txt.to(dev)
     losses = []
     for _ in range(2):                      # second step exercises static_graph's cached bucket order

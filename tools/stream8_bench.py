@@ -31,6 +31,7 @@ x = torch.randn(M, D, device=dev, generator=g).to(bf16)
 dy = torch.randn(M, D, device=dev, generator=g).to(bf16)
 h = torch.randn(M, 4 * D, device=dev, generator=g).to(bf16)
 q3 = torch.randn(M, 3 * D, device=dev, generator=g).to(bf16)
+h8 = ops.cast_e4m3(h)
 gam, bet = torch.ones(D, device=dev), torch.zeros(D, device=dev)
 ds = torch.rand(M, device=dev) + 0.5
 t = torch.ones(1, device=dev) * 4.0
@@ -59,6 +60,7 @@ cases = {
     "quantize_rows_4D_colsum": (lambda: ops.quantize_rows(h, want_colsum=True), 12 * M * D),
     "scale_quantize_rows_D": (lambda: ops.scale_quantize_rows(x, ds, t), 3 * M * D),
     "scale_quantize_rows_4D_gelu": (lambda: ops.scale_quantize_rows(h, ds, t, act=0), 12 * M * D),
+    "scale_quantize_rows_4D_gelu_in8": (lambda: ops.scale_quantize_rows(h8, ds, t, act=0), 8 * M * D),
     "ln_fwd_q8": (lambda: ops.layernorm_fwd_q8(x, gam, bet), 3 * M * D),
     "ln_fwd_q8s": (lambda: ops.layernorm_fwd_q8s(x, gam, bet, ds, t), 3 * M * D),
     "ln_fwd": (lambda: ops.layernorm_fwd(x, gam, bet), 4 * M * D),
