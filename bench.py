@@ -291,8 +291,9 @@ def main():
     ap.add_argument("--cpu-timeout", type=int, default=240)
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # no launcher around us: become one (same arguments, one rank per GPU); never returns
+    if (args.gpus > 1 or os.environ.get("CLIPA_BENCH_FORCE_DIST") == "1") and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become one (same arguments, one rank per GPU); never returns.  (CLIPA_BENCH_FORCE_DIST=1: the
+        # one-GPU rehearsal of the multi-rank path goes through the same entry)
         argv = self_launch_argv(args.gpus, sys.argv[1:])
         print("bench.py: --gpus %d without a launcher, re-executing as: %s" % (args.gpus, " ".join(argv)), file=sys.stderr, flush=True)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -11,7 +11,8 @@ extern "C" {
  * results where noted): gemm_nt 2 = main loop only, 8 = row-major tile order, bits 20..25 = tile-group size override;
  * gemm_nta / gemm_f8a 64 = epilogue stores dropped by the bounds check, 128 = every tile stores to tile 0; gemm_tn 1024 /
  * 2048 force the 16x16x32 / ping-pong kernel, 4096 / 8192 force the slice-per-XCD / tile-per-XCD work order, 16384 keeps
- * whole-tile shapes off gemm_tna, 32768 selects its schedule 1, 65536 / 131072 = its operand-fetch ablations; attention (probe
+ * whole-tile shapes off gemm_tna, 32768 selects its schedule 1, 65536 / 131072 = its (and gemm_tn8's) operand-fetch ablations; gemm_tn8
+ * bits 26..27 = 1 + schedule of tools/gen_gemm_tn8.py (0 = the default); attention (probe
  * builds with -DCLIPA_ATTN_PERSISTENT_EXPERIMENT only): 262144 / 524288 select the single-sweep backward / persistent forward of
  * tools/probes/attention_persistent/, bits 20 / 21 their timing ablations (no pair arithmetic / no output stores). */
 int clipa_internal_debug_set(int gemm_nt_variant, int ablation_flags);

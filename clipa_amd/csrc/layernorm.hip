@@ -142,6 +142,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
   }
   // (EMIT: beta is re-read per row from L1 / L2 - 4 KB shared by every wave - rather than held in NCH * 8 more registers)
   const float invD = 1.0f / (float)D;
+  // A/B knob (round 6, OFF): bf16 rows with the NEXT row's x / dy loads issued before this row's arithmetic and this row's
+  // residual gradient requested at the top instead of behind the four reductions - what lifted the LayerNorm + quantise kernels
+  // of quant.hip from 4.2 to 5.5 TB/s.  Here it costs 4-13 % (D = 1280: 1.30 -> 1.36 ms, 1024: 1.20 -> 1.25, 768: 0.44 ->
+  // 0.49; profiles/r06_stream_kernels_ln_bwd_prefetch_ab.jsonl): 152 / 210 registers for two / three chunks per lane take a
+  // wave per SIMD away.  Same values, same arithmetic either way.
+#ifndef LN_BWD_PREFETCH
+#define LN_BWD_PREFETCH 0
+#endif
+  constexpr bool PF = LN_BWD_PREFETCH && !XF32 && !YF32;
+  u32x4 nx[PF ? NCH : 1], nd[PF ? NCH : 1], nr[PF ? NCH : 1];
+  if constexpr (PF) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + c * 64;
+      nx[c] = nd[c] = u32x4{0, 0, 0, 0};
+      if (ch < nchunks && row_first < row_end) {
+        nx[c] = __builtin_nontemporal_load((const u32x4*)((const unsigned short*)x + (size_t)row_first * D + (size_t)ch * 8));
+        nd[c] = __builtin_nontemporal_load((const u32x4*)((const unsigned short*)dy + (size_t)row_first * D + (size_t)ch * 8));
+      }
+    }
+  }
   for (long r = row_first; r < row_end; r += row_step) {
     float v[NCH][8], d[NCH][8];
     float s = 0.f;
@@ -149,8 +170,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + c * 64;
       if (ch < nchunks) {
-        ld8<XF32>(x, (size_t)r * D + (size_t)ch * 8, v[c]);
-        ld8<YF32>(dy, (size_t)r * D + (size_t)ch * 8, d[c]);
+        if constexpr (PF) {
+          unpack8(nx[c], v[c]);
+          unpack8(nd[c], d[c]);
+          if (dres) nr[c] = __builtin_nontemporal_load((const u32x4*)((const unsigned short*)dres + (size_t)r * D + (size_t)ch * 8));
+          if (r + row_step < row_end) {
+            nx[c] = __builtin_nontemporal_load((const u32x4*)((const unsigned short*)x + (size_t)(r + row_step) * D + (size_t)ch * 8));
+            nd[c] = __builtin_nontemporal_load((const u32x4*)((const unsigned short*)dy + (size_t)(r + row_step) * D + (size_t)ch * 8));
+          }
+        } else {
+          ld8<XF32>(x, (size_t)r * D + (size_t)ch * 8, v[c]);
+          ld8<YF32>(dy, (size_t)r * D + (size_t)ch * 8, d[c]);
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) s += v[c][i];
       }
@@ -195,7 +226,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
         for (int i = 0; i < 8; ++i) o[i] = rstd * __builtin_fmaf(-v[c][i], m2, d[c][i] - m1);
         if (dres) {
           float rr[8];
-          ld8<XF32>(dres, (size_t)r * D + (size_t)ch * 8, rr);
+          if constexpr (PF) unpack8(nr[c], rr);
+          else ld8<XF32>(dres, (size_t)r * D + (size_t)ch * 8, rr);
 #pragma unroll
           for (int i = 0; i < 8; ++i) o[i] += rr[i];
         }

@@ -2,7 +2,7 @@
 """Convergence A/B of the reduced-precision paths: the SAME model, data, seed and optimizer trained for N steps with
 precision bf16 (all-recompute = bit-exact gradients), bf16 with the e4m3 pre-activation kept in every block (`bf16_h8`: the
 activation plan of bench.py's `value`; VERDICT r4 next #1b) and fp8 (e4m3 operands, e4m3 or e5m2 gradient operands; VERDICT r2
-item 6a) on the HIP engine, and - for the first steps - the fp32 CPU oracle (oracle/clip_oracle.py), on LEARNABLE synthetic pairs.
+item 6a; since round 6 forward, input-gradient AND weight-gradient products, `fp8_h8` additionally with bench.py's keep plan) on the HIP engine, and - for the first steps - the fp32 CPU oracle (oracle/clip_oracle.py), on LEARNABLE synthetic pairs.
 
     python tools/fp8_convergence.py --steps 200 --batch 256 > profiles/r03_fp8_convergence_S16_112.jsonl
     python tools/fp8_convergence.py --arms bf16,bf16_h8 --lr 3e-4 --seed 1 > profiles/r05_h8_convergence_S16_112_lr3e-4_seed1.jsonl
@@ -54,9 +54,9 @@ def run_engine(precision, grad_fmt, args, base, toks, length, cfg):
     dev = torch.device("cuda", 0)
     torch.manual_seed(args.seed)
     m = clipa_amd.CLIP(**cfg, output_dict=True).to(dev)
-    h8 = precision == "bf16_h8"
+    h8 = precision in ("bf16_h8", "fp8_h8")
     if h8:
-        precision = "bf16"
+        precision = precision[:-3]
     if precision in ("bf16", "fp8"):
         clipa_amd.convert_weights_to_lp(m, torch.bfloat16)
     if h8:    # bench.py's plan at the headline shape: every block keeps the e4m3 pre-activation, x1 and the attention output
@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--oracle-steps", type=int, default=12)
-    ap.add_argument("--arms", default="bf16,fp8_e4m3_grad,fp8_e5m2_grad", help="comma-separated: bf16, bf16_h8, fp8_e4m3_grad, fp8_e5m2_grad")
+    ap.add_argument("--arms", default="bf16,fp8_e4m3_grad,fp8_e5m2_grad", help="comma-separated: bf16, bf16_h8, fp8_e4m3_grad, fp8_e5m2_grad, fp8_h8 (round 6: every arm with fp8 weight gradients; fp8_h8 = bench.py's fp8 plan, the e4m3 pre-activation kept in every block)")
     args = ap.parse_args()
     import clipa_amd
     cfg = clipa_amd.get_model_config("ViT-S-16")
@@ -135,7 +135,8 @@ def main():
     cfg["text_cfg"]["context_length"] = 32
     base, toks, length = make_data(args.concepts, 112, 32, cfg["text_cfg"]["vocab_size"], 42)
     runs = {}
-    ARMS = {"bf16": ("bf16", None), "bf16_h8": ("bf16_h8", None), "fp8_e4m3_grad": ("fp8", "e4m3"), "fp8_e5m2_grad": ("fp8", "e5m2")}
+    ARMS = {"bf16": ("bf16", None), "bf16_h8": ("bf16_h8", None), "fp8_e4m3_grad": ("fp8", "e4m3"), "fp8_e5m2_grad": ("fp8", "e5m2"),
+            "fp8_h8": ("fp8_h8", "e4m3")}
     for name in args.arms.split(","):
         prec, fmt = ARMS[name]
         runs[name] = run_engine(prec, fmt, args, base, toks, length, cfg)
