@@ -146,7 +146,7 @@ def test_f8a_isa_audit(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     a = subprocess.run([sys.executable, os.path.join(ROOT, "clipa_amd", "isa_audit.py"), str(asm)], capture_output=True, text=True)
     assert a.returncode == 0, a.stdout[-3000:]
-    assert len(re.findall(r"\.name:\s+\S*gemm_f8a_kernel", asm.read_text())) == 10
+    assert len(re.findall(r"\.name:\s+\S*gemm_f8a_kernel", asm.read_text())) == 14      # 7 epilogue flavours (5 + the two e4m3 ones) x e4m3 / e5m2 A operand
 
 
 def test_audit_rejects_a_store_data_race(tmp_path):
@@ -181,3 +181,85 @@ def test_audit_counts_the_epilogue_stores(tmp_path):
     assert len(isa_audit.epilogue_store_counts("x", body(63).splitlines())) == 1
     assert len(isa_audit.epilogue_store_counts("x", body(65).splitlines())) == 1
     assert len(isa_audit.epilogue_store_counts("x", (head + st * 64 + ".Lfunc_end0:\n").splitlines())) == 1   # no markers
+
+
+def test_tn8_inc_is_up_to_date():
+    import gen_gemm_tn8 as T8
+    assert open(T8.OUT).read() == T8.render(), "run: python tools/gen_gemm_tn8.py"
+
+
+@pytest.mark.parametrize("sched", [0, 1, 2])
+def test_tn8_schedule_ordering_rules(sched):
+    """gemm_tn8 (the fp8 weight-gradient GEMM): a step is 64 MFMAs over 128 reduction rows from 128 registers of fragments that
+    are re-loaded as they die.  For every schedule of the generator, on a STEADY-STATE step (resolved against its predecessor):
+    every MFMA covers its block pair once; a block's registers are re-loaded only behind the last MFMA of the step that reads
+    them; in front of every MFMA the counted lgkmcnt wait guarantees both of its blocks have landed (checked by replaying the
+    issue order with in-order LDS returns); the ring slot is freed (barrier 1) after the step's last own read and before the first
+    LDS-DMA, the address registers are flipped between the step's own reads and the read-ahead, and the publish wait leaves exactly
+    the LDS-DMA issued before it in flight."""
+    import gen_gemm_tn8 as T8
+    S = T8.SCHEDULES[sched]
+    k = str(T8.younger(S))
+    prev = T8.step_items(S, 0, "cur", False, False, k)
+    cur = T8.step_items(S, 1, "cur", False, False, k)
+    lines = T8.resolve(prev, cur)
+    idx = lambda pred: [i for i, l in enumerate(lines) if pred(l)]
+    mf, rd = idx(lambda l: l.startswith("v_mfma")), idx(lambda l: l.startswith("ds_read_b64_tr_b8"))
+    dma, m0 = idx(lambda l: l.startswith("buffer_load")), idx(lambda l: l.startswith("s_add_u32 m0"))
+    bar, vm, flip = idx(lambda l: l == "s_barrier"), idx(lambda l: l.startswith("s_waitcnt vmcnt")), idx(lambda l: l.startswith("v_xor_b32"))
+    assert len(mf) == 64 and len(rd) == 64 and len(dma) == 16 and len(bar) == 2 and len(vm) == 1 and len(flip) == 16
+    blocks = lambda l: tuple(int(x) for x in re.findall(r"v\[(\d+):\d+\]", l)[:2])
+    pairs = {blocks(lines[i]) for i in mf}
+    assert pairs == {(128 + 8 * r, 192 + 8 * c) for r in range(8) for c in range(8)}
+    T = S["T"]
+    own = [i for i in rd if i < bar[0]]                       # the late P blocks of this step, read from its own slot at the top
+    assert len(own) == 4 * T and lines[bar[0] - 1] == "s_waitcnt lgkmcnt(0)"
+    assert max(own) < bar[0] < min(dma) and max(own) < min(flip) and max(flip) < vm[0] < bar[1] < min(i for i in rd if i > bar[0])
+    issued = sum(1 for d in dma if d < vm[0])
+    assert lines[vm[0]] == f"s_waitcnt vmcnt({issued})" and issued == T8.younger(S)
+    for d, m in zip(dma, m0):
+        assert m < d and any(m < x < d for x in mf)
+    # write-after-read inside the step: a read into a block's registers sits behind every MFMA of THIS step that reads the block,
+    # except the top reads (whose users come later in the step)
+    for i in rd:
+        lo = int(re.match(r"ds_read_b64_tr_b8 v\[(\d+):", lines[i]).group(1)) // 8 * 8
+        users = [j for j in mf if lo in blocks(lines[j])]
+        assert users
+        if i in own:
+            assert min(users) > i
+        else:
+            assert max(users) < i, lines[i]
+    # replay: LDS returns in order; `s_waitcnt lgkmcnt(n)` completes all but the n youngest reads.  Start from the predecessor's
+    # read-ahead in flight (worst case: nothing of it has returned yet).
+    seq = [l for l in T8.resolve(prev, prev)] + lines
+    base = len(seq) - len(lines)
+    inflight, landed = [], set()
+    for pos, l in enumerate(seq):
+        if l.startswith("ds_read_b64_tr_b8"):
+            r = int(re.match(r"ds_read_b64_tr_b8 v\[(\d+):", l).group(1))
+            landed.discard(r)
+            inflight.append(r)
+        elif l.startswith("s_waitcnt lgkmcnt"):
+            n = int(re.search(r"lgkmcnt\((\d+)\)", l).group(1))
+            while len(inflight) > n:
+                landed.add(inflight.pop(0))
+        elif l.startswith("v_mfma") and pos >= base:
+            for lo in blocks(l):
+                need = {lo + 2 * i for i in range(4)}
+                assert need <= landed, (sched, l, sorted(need - landed))
+    # the last step of a slice: no publish, no read-ahead
+    last = T8.resolve(prev, T8.step_items(S, 1, "nul", False, True, None))
+    assert sum(l.startswith("ds_read_b64_tr_b8") for l in last) == 4 * T and sum(l == "s_barrier" for l in last) == 1
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason="hipcc not available")
+def test_tn8_isa_audit(tmp_path):
+    asm = tmp_path / "gemm_tn8.s"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "clipa_amd", "csrc"), "-I",
+           os.path.join(ROOT, "include"), "-Wno-unused-result", "-ffp-contract=fast", "-S", "--cuda-device-only", "-o", str(asm),
+           os.path.join(ROOT, "clipa_amd", "csrc", "gemm_tn8.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a = subprocess.run([sys.executable, os.path.join(ROOT, "clipa_amd", "isa_audit.py"), str(asm)], capture_output=True, text=True)
+    assert a.returncode == 0, a.stdout[-3000:]
+    assert len(re.findall(r"\.name:\s+\S*gemm_tn8_kernel", asm.read_text())) == 6      # 3 schedules x e4m3 / e5m2 gradient operand

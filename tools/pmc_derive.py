@@ -26,7 +26,7 @@ if stats:
     for row in csv.DictReader(l for l in open(stats) if not l.startswith("#")):
         dur[row["kernel"][:70]] = float(row["avg_us"])
 for k, c in per.items():
-    if not any(s in k for s in ("gemm_nta", "gemm_tna", "attn_", "ln_fwd_kernel", "ln_bwd_kernel")):
+    if not any(s in k for s in ("gemm_nta", "gemm_tna", "gemm_tn8", "gemm_f8a", "attn_", "ln_fwd_kernel", "ln_bwd_kernel", "ln_fwd_q8", "quantize_rows")):
         continue
     out = [f"n={c['n']}"]
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:

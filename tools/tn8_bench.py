@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--shapes", default="h14")
     ap.add_argument("--schedules", default="0,1,2")
+    ap.add_argument("--orders", default="", help="comma-separated extra work orders to time with the default schedule: 4096 = slice-per-XCD forced, 8192 = tile order forced (clipa_internal_debug_set flags)")
     args = ap.parse_args()
     shapes = SHAPES["h14"] + SHAPES["l16"] if args.shapes == "all" else SHAPES[args.shapes]
     dev = "cuda"
@@ -61,6 +62,10 @@ def main():
             out = ops.gemm_tn_f8(dq, x8, t=t)
             rel = ((out - ref).norm() / ref.norm()).item()
             rec[f"f8_s{s}_ms"], rec[f"f8_s{s}_tflops"], rec[f"f8_s{s}_rel_err_vs_bf16"] = round(ms, 3), round(flops / ms / 1e9, 1), round(rel, 4)
+        for o in [int(v) for v in args.orders.split(",") if v]:
+            lib.debug_set(0, o)
+            ms = timed(lambda: ops.gemm_tn_f8(dq, x8, t=t, out_dtype=torch.bfloat16), args.iters)
+            rec[f"f8_order{o}_ms"], rec[f"f8_order{o}_tflops"] = round(ms, 3), round(flops / ms / 1e9, 1)
         lib.debug_set(0, 0)
         rec["quantize_x_ms"] = round(timed(lambda: ops.scale_quantize_rows(x, ds, t), args.iters), 3)
         print(json.dumps(rec), flush=True)
