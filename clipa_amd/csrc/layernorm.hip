@@ -307,6 +307,9 @@ int ln_fwd_grid(long rows) {
 // backward: rows per block - 128 where that still leaves >= 2048 blocks, fewer (a multiple of 4) for short inputs.
 // Rows wider than 1024 (three or four 16-byte chunks per lane, ViT-H/14's 1280) keep the persistent 1024-block grid of rounds
 // 1-3 (chunk 0): at 526 336 x 1280 the 128-row blocks measured 3.5 % slower (profiles/r04_stream_kernels_old_vs_new_lib.jsonl).
+#ifndef LN_BWD_PERSISTENT_BLOCKS
+#define LN_BWD_PERSISTENT_BLOCKS 1024         // A/B knob (tools/stream8_bench.py --lib): blocks of the persistent grid (rows wider than 1024)
+#endif
 constexpr int LN_BWD_SLICES = 16;
 int ln_bwd_chunk(long rows, long D) {
   if (D > 1024) return 0;
@@ -317,7 +320,7 @@ long ln_bwd_grid(long rows, long D) {
   const long c = ln_bwd_chunk(rows, D);
   if (c) return (rows + c - 1) / c;
   const long g = (rows + 3) / 4;
-  return g > 1024 ? 1024 : g;
+  return g > LN_BWD_PERSISTENT_BLOCKS ? LN_BWD_PERSISTENT_BLOCKS : g;
 }
 
 template <int NCH>
