@@ -211,7 +211,9 @@ __global__ void reduce_slabs_alpha_kernel(const float* __restrict__ slabs, void*
 std::once_flag g_tn8_once[MAX_DEVICES];
 int g_tn8_rc[MAX_DEVICES];
 
-constexpr int TN8_DEFAULT_SCHEDULE = 1;
+// schedule 2 (four column-major tail rows: one transposing read per MFMA slot throughout) wins 14 of the 16 production shapes by
+// 1-5 % over schedule 1 (profiles/r06_gemm_tn8_schedules_and_work_orders.jsonl)
+constexpr int TN8_DEFAULT_SCHEDULE = 2;
 
 struct TN8Plan {
   long fast_rows;      // rows the four-wave kernel covers (0: none)

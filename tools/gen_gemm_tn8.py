@@ -25,8 +25,8 @@ operands alike (which m a register byte holds is immaterial as long as P and Q a
               The next step's fragments follow the registers (gen_gemm_f8a.py): early P blocks right behind the publish
               barrier, Q block ci behind its last MFMA, the late P blocks at the top of the next step (they are needed by its
               MFMA 8 (8 - T)).  T = 1 is gen_gemm_f8a.py's order: 32 + 4 transposing reads in the last 8 MFMA slots, an LDS burst
-              of ~512 clocks against 256 of matrix work; T = 2 halves the rate (the default), T = 4 spreads the reads evenly
-              at the price of a later slot release.  Waits are counted (`lgkmcnt`: LDS returns in order; the generator walks the
+              of ~512 clocks against 256 of matrix work; T = 2 halves the rate, T = 4 spreads the reads evenly at the price of
+              a later slot release (the default: +1-5 % on 14 of 16 production shapes).  Waits are counted (`lgkmcnt`: LDS returns in order; the generator walks the
               issue order of two consecutive steps and derives every immediate).
   pipeline    as gen_gemm_f8a.py: barrier 1 (every wave has read the step's last fragments) frees the ring slot for the LDS-DMA
               of step + 2, `s_waitcnt vmcnt` + barrier 2 publish step + 1.  One tile per workgroup (split-M slices, no tile edge):
