@@ -1,3 +1,5 @@
 mkdir -p gpurun_out/r06
-(python tools/stream8_bench.py --only ln_bwd; for n in 1536 2048 3072; do python tools/stream8_bench.py --only ln_bwd --lib tools/probes/var/lnb$n.so; done) > gpurun_out/r06/stream8_f.jsonl 2>/dev/null; cat gpurun_out/r06/stream8_f.jsonl
-python tools/tn8_bench.py --shapes all --schedules 1,2 --orders 4096,8192 > gpurun_out/r06/tn8_bench_orders.jsonl 2>/dev/null; cat gpurun_out/r06/tn8_bench_orders.jsonl | cut -c1-400
+python -m pytest tests/test_fp8_gpu.py -q -s 2>&1 | grep -E "^\.?\[fp8|passed|failed|Error" > gpurun_out/r06/pytest_fp8_parity.log; tail -14 gpurun_out/r06/pytest_fp8_parity.log | cut -c1-250
+H14="--model ViT-H-14 --batch 2048 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 --exact-steps 0 --unpad-steps 0 --precision fp8 --steps 5 --warmup 2 --shapes"
+python bench.py $H14 > gpurun_out/r06/bench_h14_fp8_final_default.json 2> gpurun_out/r06/bench_h14_fp8_final_default.err; cut -c1-200 gpurun_out/r06/bench_h14_fp8_final_default.json
+python bench.py $H14 --fp8-predicted-scales > gpurun_out/r06/bench_h14_fp8_predicted_scales.json 2> gpurun_out/r06/bench_h14_fp8_predicted_scales.err; cut -c1-200 gpurun_out/r06/bench_h14_fp8_predicted_scales.json

@@ -246,6 +246,9 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "amp_bf16", "fp8"],
                     help="bf16 = reference 'bf16' mode (bf16 weights); amp_bf16 = fp32 master weights; fp8 = BASELINE "
                          "configs[3]: bf16 weights / activations, e4m3 operands for the block GEMMs (forward + input gradient)")
+    ap.add_argument("--fp8-predicted-scales", action="store_true",
+                    help="--precision fp8: the engine knob fp8_predicted_scales (the MLP's 4 D-wide tensors leave their GEMMs as e4m3 "
+                         "operands with predicted row scales; off by default: slightly lower gradient parity, DESIGN 4)")
     ap.add_argument("--keep-blocks", default="auto", help="'auto' or 'LV,LT[,MV,MT]': light-kept (and medium-kept) blocks per tower (image, text)")
     ap.add_argument("--keep-fraction", type=float, default=None,
                     help="share of the free HBM 'auto' may spend (default 0.97 single process, 0.94 with several ranks; a trial step + vote backs the plan off)")
@@ -334,6 +337,8 @@ def main():
     if args.ctx != model.positional_embedding.shape[0]:
         model.positional_embedding = torch.nn.Parameter(model.positional_embedding[:args.ctx].clone())
     model.set_grad_checkpointing(True)                         # every reference GPU script passes --grad-checkpointing
+    if args.fp8_predicted_scales:
+        model.visual.transformer.fp8_predicted_scales = model.transformer.fp8_predicted_scales = True
     model.unpad_text = bool(args.unpad_text)
     named = list(model.named_parameters())
     exclude = lambda n, p: p.ndim < 2 or "bn" in n or "ln" in n or "bias" in n or "logit_scale" in n   # main.py:311-316
@@ -813,7 +818,7 @@ def main():
             "dtype": "fp8" if args.precision == "fp8" else "bf16", "data": "synthetic",
             "config": {"workload": f"{args.model}@{args.image_size} + text-{args.ctx}, local batch {B}, "
                                    f"global batch {B * world}, " + (f"accum_freq {A} (feature cache: +1 forward per pair), " if A > 1 else "") +
-                                   f"InfoNCE local_loss+gather_with_grad, AdamW, " + ("text tower on the tokens up to EOT (unpad_text), " if args.unpad_text else "") +
+                                   f"InfoNCE local_loss+gather_with_grad, AdamW, " + ("fp8 with predicted row scales of the MLP tensors, " if args.fp8_predicted_scales else "") + ("text tower on the tokens up to EOT (unpad_text), " if args.unpad_text else "") +
                                    ("block recompute except kept tensors (image/text blocks) " + ", ".join(f"{n} {tensor_plan['v'][n]}/{tensor_plan['t'][n]}" for n in (("h8",) if use_l8 else ()) + ("a", "x1", "qkv") + (() if use_l8 else ("h",))) if tensor_plan is not None else f"block recompute except {int(keep_v)}+{int(keep_t)} {'light8' if use_l8 else 'light'}-kept and {int(med_v)}+{int(med_t)} medium-kept (image+text) blocks"), "precision": args.precision, "parallelism": f"dp{world}" + ("" if args.optimizer == "adamw" else f" zero1/{args.exchange}"),
                        "global_batch": B * world, "train_gflop_per_pair": round(gf, 2)},
             # executed model FLOPs (the reference count less the dead rows of the pruned last blocks) against the peak of the

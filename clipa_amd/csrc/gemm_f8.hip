@@ -223,10 +223,44 @@ int ensure_f8_attrs(int dev) {
 
 using namespace clipa_gemm;
 
+namespace {
+int gemm_nt_f8_impl(const void* A8, const void* B8, const float* scale_a, const float* scale_b, void* C, void* C2, const float* bias,
+                    const void* aux, const float* scale_out, float* colsum_partial, int outq, int64_t M, int64_t N, int64_t K,
+                    int64_t lda, int64_t ldb, int64_t ldc, int64_t ldaux, float alpha, int epi, int act, int fmt_a, int fmt_b,
+                    void* stream);
+}
+
 extern "C" int clipa_gemm_nt_f8(const void* A8, const void* B8, const float* scale_a, const float* scale_b, void* C,
                                 void* C2, const float* bias, const void* aux, int64_t M, int64_t N, int64_t K,
                                 int64_t lda, int64_t ldb, int64_t ldc, int64_t ldaux, float alpha, int epi, int act,
                                 int fmt_a, int fmt_b, void* stream) {
+  return gemm_nt_f8_impl(A8, B8, scale_a, scale_b, C, C2, bias, aux, nullptr, nullptr, 0, M, N, K, lda, ldb, ldc, ldaux, alpha, epi,
+                         act, fmt_a, fmt_b, stream);
+}
+
+// The producer-quantised form (round 6): C8 = e4m3(epi(...) rounded to bf16, row m times scale_out[m]) - the fp8 operand of the NEXT
+// GEMM written by this one's epilogue, with a row scale the caller predicted (engine._row_bound) - and, for CLIPA_EPI_DACT8, the
+// partial column sums of the unscaled outputs ([M / 128][N] floats; clipa_reduce_partial_rows adds them up: the bias gradient).
+extern "C" int clipa_gemm_nt_f8q(const void* A8, const void* B8, const float* scale_a, const float* scale_b, void* C8, void* C2,
+                                 const float* bias, const void* aux, const float* scale_out, float* colsum_partial, int64_t M,
+                                 int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldaux, float alpha, int epi,
+                                 int act, int fmt_a, void* stream) {
+  if (M <= 0 || N <= 0) return CLIPA_OK;
+  if (!(epi == CLIPA_EPI_ACT || epi == CLIPA_EPI_ACT_PRE8 || epi == CLIPA_EPI_DACT8)) { clipa_set_error("gemm_nt_f8q: epilogue %d has no quantised-output form (CLIPA_EPI_ACT, _ACT_PRE8, _DACT8)", epi); return CLIPA_ERR_ARG; }
+  if (!scale_out) { clipa_set_error("gemm_nt_f8q: scale_out is required"); return CLIPA_ERR_ARG; }
+  if (epi == CLIPA_EPI_DACT8 && (!scale_a || !scale_b)) { clipa_set_error("gemm_nt_f8q: CLIPA_EPI_DACT8 needs both scale vectors"); return CLIPA_ERR_ARG; }
+  if (epi == CLIPA_EPI_DACT8 && bias) { clipa_set_error("gemm_nt_f8q: CLIPA_EPI_DACT8 takes no bias (an input-gradient product)"); return CLIPA_ERR_ARG; }
+  if (epi == CLIPA_EPI_DACT8 && !colsum_partial) { clipa_set_error("gemm_nt_f8q: CLIPA_EPI_DACT8 needs colsum_partial ([M / 128][N] floats)"); return CLIPA_ERR_ARG; }
+  if (!f8a_eligible(M, N, K, 0)) { clipa_set_error("gemm_nt_f8q: whole-tile shapes only (M, N %% 256 == 0, K %% 256 == 0, K >= 512)"); return CLIPA_ERR_ARG; }
+  return gemm_nt_f8_impl(A8, B8, scale_a, scale_b, C8, C2, bias, aux, scale_out, colsum_partial, 1, M, N, K, lda, ldb, ldc, ldaux, alpha,
+                         epi, act, fmt_a, 0, stream);
+}
+
+namespace {
+int gemm_nt_f8_impl(const void* A8, const void* B8, const float* scale_a, const float* scale_b, void* C, void* C2, const float* bias,
+                    const void* aux, const float* scale_out, float* colsum_partial, int outq, int64_t M, int64_t N, int64_t K,
+                    int64_t lda, int64_t ldb, int64_t ldc, int64_t ldaux, float alpha, int epi, int act, int fmt_a, int fmt_b,
+                    void* stream) {
   if (M <= 0 || N <= 0) return CLIPA_OK;
   if (K <= 0 || K % 16 != 0) { clipa_set_error("gemm_nt_f8: K=%ld must be a positive multiple of 16", (long)K); return CLIPA_ERR_ARG; }
   if (lda % 16 != 0 || ldb % 16 != 0) { clipa_set_error("gemm_nt_f8: lda, ldb must be multiples of 16 bytes"); return CLIPA_ERR_ARG; }
@@ -255,11 +289,12 @@ extern "C" int clipa_gemm_nt_f8(const void* A8, const void* B8, const float* sca
   hipStream_t st = (hipStream_t)stream;
   // whole-tile shapes with e4m3 weights (every block GEMM of the BASELINE configurations) run on the four-wave kernel with the
   // hand-scheduled main loop (gemm_f8a.hip); bit-identical outputs.  clipa_internal_debug_set(1, .) keeps them on this file's kernel.
-  if (pre8 || aux8 || (g_nt_variant.load(std::memory_order_relaxed) != 1 && !(a.abl & 13) && f8a_eligible(M, N, K, fmt_b))) {
+  if (outq || pre8 || aux8 || (g_nt_variant.load(std::memory_order_relaxed) != 1 && !(a.abl & 13) && f8a_eligible(M, N, K, fmt_b))) {
     F8AArgs b;
     b.A = a.A; b.B = a.B; b.C = a.C; b.C2 = a.C2; b.bias = a.bias; b.aux = a.aux; b.sa = a.sa; b.sb = a.sb;
     b.M = a.M; b.N = a.N; b.K = a.K; b.lda = a.lda; b.ldb = a.ldb; b.ldc = a.ldc; b.ldaux = a.ldaux;
     b.alpha = a.alpha; b.epi = a.epi; b.act = a.act; b.abl = a.abl; b.gm = a.gm; b.pre8 = pre8; b.aux8 = aux8;
+    b.so = scale_out; b.cs_part = colsum_partial; b.outq = outq;
     return f8a_launch(b, fmt_a, dev, num_cu, st);
   }
   note_gemm(7);
@@ -280,3 +315,5 @@ extern "C" int clipa_gemm_nt_f8(const void* A8, const void* B8, const float* sca
 #undef LAUNCH_F8
   return clipa_check_launch("gemm_nt_f8");
 }
+}  // namespace
+

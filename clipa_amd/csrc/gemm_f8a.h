@@ -11,6 +11,9 @@ struct F8AArgs {
   long lda, ldb, ldc, ldaux;            // A, B: bytes; C, aux: elements
   float alpha;
   int epi, act, abl, gm;
+  const float* so;                      // OUTQ: per-row output scale [M] (the e4m3 output of row m is the bf16 result times so[m]); NULL = 1
+  float* cs_part;                       // OUTQ == 2 (DACT): [M / 128][N] partial column sums of the unscaled outputs
+  int outq;                             // C holds e4m3 bytes (1 byte per element, row stride ldc BYTES)
   int pre8, aux8;                       // C2 / aux hold e4m3 bytes (1 byte per element, row strides ldc / ldaux in BYTES): CLIPA_EPI_ACT_PRE8 / CLIPA_EPI_DACT8
 };
 

@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const char* __restri
 // partial rows in a fixed order (bit-reproducible, no atomics).
 template <int NCH, int FMT>
 __global__ __launch_bounds__(256) void quantize_rows_colsum_kernel(const char* __restrict__ x, long ldx, char* __restrict__ q, long ldq,
-                                                                   float* __restrict__ dq, float* __restrict__ partial, long rows, int K) {
+                                                                   float* __restrict__ dq, float* __restrict__ partial, float* __restrict__ rnorm,
+                                                                   long rows, int K) {
   __shared__ float red[4][512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long wid = (long)blockIdx.x * 4 + wave;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void quantize_rows_colsum_kernel(const char* _
   }
   for (long row = wid; row < rows; row += nw) {
     u32x4 v[NCH];
-    float amax = 0.f;
+    float amax = 0.f, ssq = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + c * 64;
@@ -128,13 +129,17 @@ __global__ __launch_bounds__(256) void quantize_rows_colsum_kernel(const char* _
         float f[8];
         unpack8(v[c], f);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { amax = fmaxf(amax, fabsf(f[i])); cs[c][i] += f[i]; }
+        for (int i = 0; i < 8; ++i) { amax = fmaxf(amax, fabsf(f[i])); cs[c][i] += f[i]; ssq = __builtin_fmaf(f[i], f[i], ssq); }
       }
     }
     amax = wave_max(amax);
     float s, d;
     row_scales<FMT>(amax, s, d);
     if (lane == 0) dq[row] = d;
+    if (rnorm) {      // ||x[row,:]||_2 (engine._row_bound: the Cauchy-Schwarz bound of the input gradient this row produces)
+      const float n2 = wave_sum(ssq);
+      if (lane == 0) rnorm[row] = sqrtf(n2);
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + c * 64;
@@ -182,7 +187,8 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restr
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_q8_kernel(const char* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, char* __restrict__ y,
-                                                        char* __restrict__ q, float* __restrict__ dq, long rows, int D, float eps) {
+                                                        char* __restrict__ q, float* __restrict__ dq, float* __restrict__ rnorm,
+                                                        long rows, int D, float eps) {
   const int lane = threadIdx.x & 63;
   const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long nw = (long)gridDim.x * 4;
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(256) void ln_fwd_q8_kernel(const char* __restrict__
       }
     }
     const float rstd = rsqrtf(__builtin_fmaf(wave_sum(ss), invD, eps));      // (layernorm.hip: the expressions of ln_fwd_kernel, fused multiply-adds written out)
-    float amax = 0.f;
+    float amax = 0.f, ssq = 0.f;
     u32x4 yb[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -249,13 +255,17 @@ __global__ __launch_bounds__(256) void ln_fwd_q8_kernel(const char* __restrict__
         if (y) st_stream<u32x4>(y + ((size_t)r * D + (size_t)ch * 8) * 2, yb[c]);
         unpack8(yb[c], o);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(o[i]));
+        for (int i = 0; i < 8; ++i) { amax = fmaxf(amax, fabsf(o[i])); ssq = __builtin_fmaf(o[i], o[i], ssq); }
       }
     }
     amax = wave_max(amax);
     float s, d;
     row_scales<0>(amax, s, d);
     if (lane == 0) dq[r] = d;
+    if (rnorm) {      // ||y[r,:]||_2: with the next layer's largest weight-row norm a Cauchy-Schwarz bound of that layer's outputs (engine._row_bound)
+      const float n2 = wave_sum(ssq);
+      if (lane == 0) rnorm[r] = sqrtf(n2);
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + c * 64;
@@ -304,13 +314,13 @@ long quant_colsum_blocks(long rows) {
   return b < 1 ? 1 : b;
 }
 template <int FMT>
-int launch_quant_colsum(const void* x, void* q, float* dq, float* colsum, float* partial, int64_t rows, int64_t K, int64_t ldx,
+int launch_quant_colsum(const void* x, void* q, float* dq, float* colsum, float* rownorm, float* partial, int64_t rows, int64_t K, int64_t ldx,
                         int64_t ldq, hipStream_t st) {
   const long nb = quant_colsum_blocks(rows);
   const dim3 grid((unsigned)nb), block(256);
   const char* xp = (const char*)x;
   char* qp = (char*)q;
-#define QC_LAUNCH(N) hipLaunchKernelGGL((quantize_rows_colsum_kernel<N, FMT>), grid, block, 0, st, xp, (long)ldx, qp, (long)ldq, dq, partial, (long)rows, (int)K)
+#define QC_LAUNCH(N) hipLaunchKernelGGL((quantize_rows_colsum_kernel<N, FMT>), grid, block, 0, st, xp, (long)ldx, qp, (long)ldq, dq, partial, rownorm, (long)rows, (int)K)
   if (K <= 512) QC_LAUNCH(1);
   else if (K <= 1024) QC_LAUNCH(2);
   else if (K <= 1536) QC_LAUNCH(3);
@@ -326,12 +336,20 @@ int launch_quant_colsum(const void* x, void* q, float* dq, float* colsum, float*
 }
 }  // namespace
 
+extern "C" int clipa_reduce_partial_rows(const float* partial, float* out, int64_t nrows, int64_t K, void* stream) {
+  if (K <= 0 || K % 4 != 0) { clipa_set_error("reduce_partial_rows: K must be a positive multiple of 4"); return CLIPA_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  if (nrows <= 0) { (void)hipMemsetAsync(out, 0, K * sizeof(float), st); return CLIPA_OK; }
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((K + 63) / 64)), dim3(256), 0, st, partial, out, (int)nrows, (int)K);
+  return clipa_check_launch("reduce_partial_rows");
+}
+
 extern "C" int64_t clipa_quantize_rows_colsum_workspace(int64_t rows, int64_t K) {
   return quant_colsum_blocks(rows) * K * (int64_t)sizeof(float);
 }
 
-extern "C" int clipa_quantize_rows_colsum(const void* x, void* q, float* dq, float* colsum, int64_t rows, int64_t K, int64_t ldx,
-                                          int64_t ldq, int fmt, void* workspace, int64_t workspace_bytes, void* stream) {
+extern "C" int clipa_quantize_rows_colsum(const void* x, void* q, float* dq, float* colsum, float* rownorm, int64_t rows, int64_t K,
+                                          int64_t ldx, int64_t ldq, int fmt, void* workspace, int64_t workspace_bytes, void* stream) {
   if (K <= 0 || K % 8 != 0 || K > 8192) { clipa_set_error("quantize_rows_colsum: K=%ld must be a multiple of 8 in (0, 8192]", (long)K); return CLIPA_ERR_ARG; }
   if (ldx % 8 != 0 || ldq % 8 != 0 || ldx < K || ldq < K) { clipa_set_error("quantize_rows_colsum: ldx, ldq must be multiples of 8 and >= K"); return CLIPA_ERR_ARG; }
   if (fmt != 0 && fmt != 1) { clipa_set_error("quantize_rows_colsum: fmt is 0 (e4m3) or 1 (e5m2)"); return CLIPA_ERR_ARG; }
@@ -339,12 +357,18 @@ extern "C" int clipa_quantize_rows_colsum(const void* x, void* q, float* dq, flo
   hipStream_t st = (hipStream_t)stream;
   if (rows <= 0) { (void)hipMemsetAsync(colsum, 0, K * sizeof(float), st); return CLIPA_OK; }
   if (!workspace || workspace_bytes < clipa_quantize_rows_colsum_workspace(rows, K)) { clipa_set_error("quantize_rows_colsum: workspace too small"); return CLIPA_ERR_ARG; }
-  return fmt == 0 ? launch_quant_colsum<0>(x, q, dq, colsum, (float*)workspace, rows, K, ldx, ldq, st)
-                  : launch_quant_colsum<1>(x, q, dq, colsum, (float*)workspace, rows, K, ldx, ldq, st);
+  return fmt == 0 ? launch_quant_colsum<0>(x, q, dq, colsum, rownorm, (float*)workspace, rows, K, ldx, ldq, st)
+                  : launch_quant_colsum<1>(x, q, dq, colsum, rownorm, (float*)workspace, rows, K, ldx, ldq, st);
 }
 
+extern "C" int clipa_layernorm_fwd_q8n(const void* x, const float* gamma, const float* beta, void* y, void* q, float* dq,
+                                       float* rownorm, int64_t rows, int64_t D, float eps, void* stream);
 extern "C" int clipa_layernorm_fwd_q8(const void* x, const float* gamma, const float* beta, void* y, void* q, float* dq,
                                       int64_t rows, int64_t D, float eps, void* stream) {
+  return clipa_layernorm_fwd_q8n(x, gamma, beta, y, q, dq, nullptr, rows, D, eps, stream);
+}
+extern "C" int clipa_layernorm_fwd_q8n(const void* x, const float* gamma, const float* beta, void* y, void* q, float* dq,
+                                       float* rownorm, int64_t rows, int64_t D, float eps, void* stream) {
   if (rows <= 0) return CLIPA_OK;
   if (D <= 0 || D % 8 != 0 || D > 2048) { clipa_set_error("layernorm_fwd_q8: D=%ld must be a multiple of 8 in (0, 2048]", (long)D); return CLIPA_ERR_ARG; }
   // 8192 blocks striding the rows: at 806 912 x 1024 / 526 336 x 1280 / 157 696 x 1280 the persistent 2048 blocks of rounds
@@ -355,10 +379,10 @@ extern "C" int clipa_layernorm_fwd_q8(const void* x, const float* gamma, const f
   const dim3 grid((unsigned)blocks), block(256);
   hipStream_t st = (hipStream_t)stream;
   const char* xp = (const char*)x;
-  if (D <= 512) hipLaunchKernelGGL((ln_fwd_q8_kernel<1>), grid, block, 0, st, xp, gamma, beta, (char*)y, (char*)q, dq, (long)rows, (int)D, eps);
-  else if (D <= 1024) hipLaunchKernelGGL((ln_fwd_q8_kernel<2>), grid, block, 0, st, xp, gamma, beta, (char*)y, (char*)q, dq, (long)rows, (int)D, eps);
-  else if (D <= 1536) hipLaunchKernelGGL((ln_fwd_q8_kernel<3>), grid, block, 0, st, xp, gamma, beta, (char*)y, (char*)q, dq, (long)rows, (int)D, eps);
-  else hipLaunchKernelGGL((ln_fwd_q8_kernel<4>), grid, block, 0, st, xp, gamma, beta, (char*)y, (char*)q, dq, (long)rows, (int)D, eps);
+  if (D <= 512) hipLaunchKernelGGL((ln_fwd_q8_kernel<1>), grid, block, 0, st, xp, gamma, beta, (char*)y, (char*)q, dq, rownorm, (long)rows, (int)D, eps);
+  else if (D <= 1024) hipLaunchKernelGGL((ln_fwd_q8_kernel<2>), grid, block, 0, st, xp, gamma, beta, (char*)y, (char*)q, dq, rownorm, (long)rows, (int)D, eps);
+  else if (D <= 1536) hipLaunchKernelGGL((ln_fwd_q8_kernel<3>), grid, block, 0, st, xp, gamma, beta, (char*)y, (char*)q, dq, rownorm, (long)rows, (int)D, eps);
+  else hipLaunchKernelGGL((ln_fwd_q8_kernel<4>), grid, block, 0, st, xp, gamma, beta, (char*)y, (char*)q, dq, rownorm, (long)rows, (int)D, eps);
   return clipa_check_launch("layernorm_fwd_q8");
 }
 
@@ -482,6 +506,72 @@ __global__ __launch_bounds__(256) void ln_fwd_q8s_kernel(const char* __restrict_
 }
 
 }  // namespace
+
+// ---- predicted row scales (producer-fused quantisation, gemm_f8a.hip OUTQ) ---------------------------------------------------
+// |sum_k a[m,k] w[n,k] + b[n]| <= ||a[m,:]||_2 * max_n ||w[n,:]||_2 + max_n |b[n]|: a bound of every output of row m that is known
+// BEFORE the GEMM runs, from the row norm its producer returns and two scalars of the weights (once per optimizer step).
+namespace {
+// out[0] = max_r ||w[r,:]||_2 (w bf16 [rows, K]); one wave per row
+__global__ __launch_bounds__(256) void rownorm_max_kernel(const unsigned short* __restrict__ w, long ld, long rows, int K, unsigned* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long nw = (long)gridDim.x * 4;
+  float best = 0.f;
+  for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += nw) {
+    float ss = 0.f;
+    for (int c = lane * 8; c < K; c += 512) {
+      float f[8];
+      unpack8(*(const u32x4*)(w + (size_t)r * ld + c), f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ss = __builtin_fmaf(f[i], f[i], ss);
+    }
+    best = fmaxf(best, sqrtf(wave_sum(ss)));
+  }
+  if (lane == 0) atomicMax(out, __float_as_uint(best));
+}
+__global__ void absmax_kernel(const float* __restrict__ v, long n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(v[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+// bound[m] = factor * rn[m] * wn[0] + bn[0];  scale[m] = bound / 448 (the de-quantisation scale of the row: 0 for a zero row),
+// inv[m] = 448 / bound (what the producing epilogue multiplies by; 0 for a zero row)
+__global__ void row_bound_kernel(const float* __restrict__ rn, const float* __restrict__ wn, const float* __restrict__ bn, float factor,
+                                 float* __restrict__ scale, float* __restrict__ inv, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float b = __builtin_fmaf(factor * rn[i], wn[0], bn ? bn[0] : 0.f);
+  scale[i] = b > 0.f ? b * (1.0f / 448.0f) : 0.f;
+  inv[i] = b > 0.f ? 448.0f / b : 0.f;
+}
+}  // namespace
+
+extern "C" int clipa_rownorm_max(const void* w, int64_t rows, int64_t K, int64_t ld, float* out, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (K <= 0 || K % 8 != 0 || ld % 8 != 0 || ld < K) { clipa_set_error("rownorm_max: K, ld must be multiples of 8, ld >= K"); return CLIPA_ERR_ARG; }
+  if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) { clipa_set_error("rownorm_max: hipMemsetAsync failed"); return CLIPA_ERR_LAUNCH; }
+  if (rows <= 0) return CLIPA_OK;
+  long blocks = (rows + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(rownorm_max_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const unsigned short*)w, (long)ld, (long)rows, (int)K, (unsigned*)out);
+  return clipa_check_launch("rownorm_max");
+}
+extern "C" int clipa_absmax_f32(const float* v, int64_t n, float* out, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) { clipa_set_error("absmax_f32: hipMemsetAsync failed"); return CLIPA_ERR_LAUNCH; }
+  if (n <= 0) return CLIPA_OK;
+  long blocks = (n + 1023) / 1024;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, v, (long)n, (unsigned*)out);
+  return clipa_check_launch("absmax_f32");
+}
+extern "C" int clipa_row_bound(const float* rownorm, const float* wnorm_dev, const float* bmax_dev, float factor, float* scale, float* inv,
+                               int64_t n, void* stream) {
+  if (n <= 0) return CLIPA_OK;
+  if (!rownorm || !wnorm_dev || !scale || !inv) { clipa_set_error("row_bound: rownorm, wnorm, scale and inv are required"); return CLIPA_ERR_ARG; }
+  hipLaunchKernelGGL(row_bound_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rownorm, wnorm_dev, bmax_dev, factor, scale, inv, (long)n);
+  return clipa_check_launch("row_bound");
+}
 
 extern "C" int clipa_rowscale_max(const float* a, const float* b, int64_t n, float* out, void* stream) {
   hipStream_t st = (hipStream_t)stream;

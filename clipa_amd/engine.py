@@ -23,6 +23,7 @@ from . import ops
 bf16, f32 = torch.bfloat16, torch.float32
 
 
+
 class WeightCache:
     """bf16 operand copies of the parameters ([N,K] forward form and [K,N] transposed form for the
     input-gradient GEMMs), refreshed when the parameter's version counter changes (i.e. once per
@@ -181,14 +182,27 @@ def _block_forward_fp8(x, P, cfg, keep, need_y=True, scales=None):
     qa, sa = ops.quantize_rows(a)
     x1 = _lin8(qa, sa, P, "out", epi=ops.EPI_ADD, aux=x)
     del qa
-    h2, q2, s2 = ops.layernorm_fwd_q8(x1, P["ln2_w"], P["ln2_b"], cfg["eps"], want_bf16=full)
-    want_pre = "e4m3" if "h8" in ks else ("h" in ks)
-    if want_pre:
-        g, hpre = _lin8(q2, s2, P, "fc", epi=ops.EPI_ACT, act=act, want_pre=want_pre)
+    h2, q2, s2, rn2 = ops.layernorm_fwd_q8(x1, P["ln2_w"], P["ln2_b"], cfg["eps"], want_bf16=full, want_rownorm=True)      # (the row norms: 4 bytes per row)
+    want_pre = "e4m3" if "h8" in ks else ("h" in ks or full)
+    # Engine knob `fp8_predicted_scales` (round 6, off by default): the activation leaves the c_fc GEMM as the e4m3 operand of
+    # c_proj (no bf16 copy, no row quantiser pass).  A tile of the GEMM cannot know its row's maximum, so the row scale is PREDICTED: |h[m,c]| <= ||LN2(x1)[m,:]|| * max_c ||W_fc[c,:]|| +
+    # max |b_fc| (Cauchy-Schwarz; 1.13 covers the e4m3 rounding of both operands) and |gelu(h)| <= |h| - a rigorous bound, a few
+    # binades above the row's true maximum, well inside e4m3's range.  Every tier uses the same scales (bit-identical forwards);
+    # ragged shapes / the all-stored mode run GEMM + scaled quantiser with the same arithmetic.  Price (tests/test_fp8_gpu.py,
+    # DESIGN 4): per-tensor gradient cosines against the fp32 reference 0.001-0.009 lower than with the rows' true maxima.
+    sg, so = ops.row_bound(rn2, P["wn_fc"], P["bmax_fc"], 1.13) if cfg.get("fp8_predict") else (None, None)
+    if not cfg.get("fp8_predict"):      # the default: bf16 activation + a row quantiser with the row's TRUE maximum
+        r = _lin8(q2, s2, P, "fc", epi=ops.EPI_ACT, act=act, want_pre=want_pre)
+        g, hpre = r if want_pre else (r, None)
+        qg, sg = ops.quantize_rows(g)
+        g = g if full else None
+    elif full:
+        g, hpre = _lin8(q2, s2, P, "fc", epi=ops.EPI_ACT, act=act, want_pre=True)
+        qg = ops.scale_quantize_rows(g, so, P["one"])
     else:
-        g, hpre = _lin8(q2, s2, P, "fc", epi=ops.EPI_ACT, act=act), None
+        r = _lin8(q2, s2, P, "fc", epi=ops.EPI_ACT, act=act, want_pre=want_pre, out_scale=so)
+        (qg, hpre), g = (r if want_pre else (r, None)), None
     del q2
-    qg, sg = ops.quantize_rows(g)
     y = _lin8(qg, sg, P, "proj", epi=ops.EPI_ADD, aux=x1)
     del qg
     sc = (s1, sa, s2, sg)
@@ -230,15 +244,24 @@ def _block_backward_fp8(x, dy, box, P, cfg, scales):
     h1, qkv, a, stats, x1, h2, hpre, g = box.pop()
     s1, sa, s2, sg = scales
     dy = dy.contiguous()
+    fmt = cfg.get("fp8_grad_fmt", ops.FMT_E4M3)
     # y = x1 + c_proj(gelu(hpre))
-    dq, ds, d_b_proj = _gradq8(dy, cfg)
+    dq, ds, d_b_proj, rn = ops.quantize_rows(dy, fmt, want_colsum=True, want_rownorm=True)
     emit_g = (lambda r, t: ops.scale_quantize_rows(g, r, t)) if g is not None else (lambda r, t: ops.scale_quantize_rows(hpre, r, t, act=act))
     d_w_proj = _wgrad8(dq, ds, sg, emit_g, P["dt_w_proj"], cfg)
     del g
-    dh = _dlin8(dq, ds, P, "proj", cfg, epi=ops.EPI_DACT, act=act, aux=hpre)     # [M,4D]
-    del hpre, dq, ds
-    dq, ds, d_b_fc = _gradq8(dh, cfg)
-    del dh
+    if fmt == ops.FMT_E4M3 and cfg.get("fp8_predict"):
+        # the gradient of the pre-activation leaves the GEMM as the e4m3 operand of the next two products, with its column sums
+        # (the bias gradient of c_fc) from the same epilogue; row scale predicted as in the forward: |dh[m,c]| <=
+        # ||dy[m,:]|| * max_c ||W_proj[:,c]|| * max gelu' (1.13), times 1.13 for the operands' rounding
+        sdh, sodh = ops.row_bound(rn, P["wn_projT"], None, 1.13 * 1.13)
+        dq, d_b_fc = _dlin8(dq, ds, P, "proj", cfg, epi=ops.EPI_DACT, act=act, aux=hpre, out_scale=sodh, want_colsum=True)
+        ds = sdh
+    else:   # e5m2 gradient bytes: bf16 gradient + the row quantiser
+        dh = _dlin8(dq, ds, P, "proj", cfg, epi=ops.EPI_DACT, act=act, aux=hpre)     # [M,4D]
+        dq, ds, d_b_fc = _gradq8(dh, cfg)
+        del dh
+    del hpre
     emit_h2 = (lambda r, t: ops.scale_quantize_rows(h2, r, t)) if h2 is not None else \
         (lambda r, t: ops.layernorm_fwd_q8s(x1, P["ln2_w"], P["ln2_b"], r, t, eps))
     d_w_fc = _wgrad8(dq, ds, s2, emit_h2, P["dt_w_fc"], cfg)
@@ -345,6 +368,14 @@ def _block_operands(params, cache, fp8=False, fp8_names=("in", "out", "fc", "pro
                 continue
             P["w8_" + name] = cache.custom(w, "w8", lambda t, w=w: ops.quantize_rows(cache.w(w)))
             P["wt8_" + name] = cache.custom(w, "wt8", lambda t, w=w: ops.quantize_rows(cache.wt(w)))
+        P["one"] = cache.custom(w_in, "one", lambda t: torch.ones(1, device=t.device, dtype=f32))
+        if "fc" in fp8_names:
+            # the two scalars per layer behind the PREDICTED row scales of the MLP's 4 D-wide products (_row_bound): the largest
+            # row norm of c_fc.weight and |c_fc.bias| bound the pre-activation, the largest row norm of c_proj.weight^T the
+            # gradient that comes back through c_proj; device scalars, refreshed with the operand copies once per optimizer step
+            P["wn_fc"] = cache.custom(w_fc, "wn", lambda t: ops.rownorm_max(cache.w(w_fc)))
+            P["bmax_fc"] = cache.custom(b_fc, "bmax", lambda t: ops.absmax(cache.f32(b_fc)))
+            P["wn_projT"] = cache.custom(w_proj, "wnT", lambda t: ops.rownorm_max(cache.wt(w_proj)))
     return P
 
 

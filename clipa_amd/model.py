@@ -165,6 +165,10 @@ class Transformer(nn.Module):
         # forward and input-gradient GEMMs on e4m3 operands (engine._block_forward_fp8); "e5m2" switches the gradient operand
         self.fp8 = False
         self.fp8_grad_format = "e4m3"
+        # fp8 engine knob (round 6, off): the two 4 D-wide MLP tensors (activation, pre-activation gradient) leave their GEMMs as
+        # e4m3 operands with PREDICTED row scales (a Cauchy-Schwarz bound from the producer's row norm and the weight's largest
+        # row norm) instead of bf16 + a row quantiser: ~5 % faster, per-tensor gradient cosines 0.001-0.009 lower
+        self.fp8_predicted_scales = False
         self.resblocks = nn.ModuleList([_ResBlockParams(width, heads, mlp_ratio) for _ in range(layers)])
 
     def get_cast_dtype(self):
@@ -177,7 +181,8 @@ class Transformer(nn.Module):
             _unsupported(f"causal attention with head dim {self.width // self.heads} (the wide heads are compiled for image towers)")
         base = {"B": B, "L": L, "H": self.heads, "causal": bool(causal), "act": self.act, "eps": 1e-5,
                 "recompute": bool(self.grad_checkpointing), "keep": "light", "fp8": bool(self.fp8),
-                "fp8_grad_fmt": ops.FMT_E5M2 if self.fp8_grad_format == "e5m2" else ops.FMT_E4M3, "varlen": varlen}
+                "fp8_grad_fmt": ops.FMT_E5M2 if self.fp8_grad_format == "e5m2" else ops.FMT_E4M3,
+                "fp8_predict": bool(self.fp8 and self.fp8_predicted_scales), "varlen": varlen}
         kept, medium = dict(base, keep_this=True), dict(base, keep_this=True, keep="medium")
         light8 = dict(base, keep_this=True, keep="light8")
         n1, n2 = self.keep_blocks, self.keep_blocks + self.light8_blocks

@@ -175,9 +175,10 @@ FMT_E4M3, FMT_E5M2 = 0, 1
 u8 = torch.uint8
 
 
-def quantize_rows(x, fmt=FMT_E4M3, want_colsum=False):
+def quantize_rows(x, fmt=FMT_E4M3, want_colsum=False, want_rownorm=False):
     """Row-scaled fp8 operand of a bf16 matrix: -> (q uint8 [M,K] holding OCP e4m3 / e5m2 bytes, dq f32 [M]) with
-    x[r,:] ~ dq[r] * fp8(q[r,:]).  want_colsum: also sum_r x[r,:] (f32 [K]; the bias gradient when x is a layer's dY)."""
+    x[r,:] ~ dq[r] * fp8(q[r,:]).  want_colsum: also sum_r x[r,:] (f32 [K]; the bias gradient when x is a layer's dY);
+    want_rownorm (with want_colsum): also ||x[r,:]||_2 (f32 [M]: the row bound of the product this gradient feeds, row_bound)."""
     _chk(x, bf16, "x", 2)
     x, ld = _rowmajor(x)
     M, K = x.shape
@@ -185,18 +186,20 @@ def quantize_rows(x, fmt=FMT_E4M3, want_colsum=False):
     dq = torch.empty(M, device=x.device, dtype=f32)
     if want_colsum:
         cs = torch.empty(K, device=x.device, dtype=f32)
+        rn = torch.empty(M, device=x.device, dtype=f32) if want_rownorm else None
         wsb = lib.query("clipa_quantize_rows_colsum_workspace", M, K)
         ws = torch.empty(max(wsb, 4) // 4, device=x.device, dtype=f32)
         with _Timed("quantize_rows", 0.0, 3.0 * M * K, f"{M},{K},+colsum"):
-            lib.call("clipa_quantize_rows_colsum", _p(x), _p(q), _p(dq), _p(cs), M, K, ld, K, int(fmt), _p(ws), wsb, _stream())
-        return q, dq, cs
+            lib.call("clipa_quantize_rows_colsum", _p(x), _p(q), _p(dq), _p(cs), _p(rn), M, K, ld, K, int(fmt), _p(ws), wsb, _stream())
+        return (q, dq, cs, rn) if want_rownorm else (q, dq, cs)
     with _Timed("quantize_rows", 0.0, 3.0 * M * K, f"{M},{K}"):
         lib.call("clipa_quantize_rows", _p(x), _p(q), _p(dq), M, K, ld, K, int(fmt), _stream())
     return q, dq
 
 
-def layernorm_fwd_q8(x, gamma, beta, eps=1e-5, want_bf16=False):
-    """LayerNorm of bf16 rows emitting the e4m3 operand of the next GEMM: -> (y bf16 | None, q uint8, dq f32 [rows])."""
+def layernorm_fwd_q8(x, gamma, beta, eps=1e-5, want_bf16=False, want_rownorm=False):
+    """LayerNorm of bf16 rows emitting the e4m3 operand of the next GEMM: -> (y bf16 | None, q uint8, dq f32 [rows]) (+ the rows'
+    L2 norms, f32 [rows], with want_rownorm)."""
     _chk(x, bf16, "x")
     _chk(gamma, f32, "gamma", 1)
     _chk(beta, f32, "beta", 1)
@@ -206,9 +209,10 @@ def layernorm_fwd_q8(x, gamma, beta, eps=1e-5, want_bf16=False):
     y = torch.empty(x.shape, device=x.device, dtype=bf16) if want_bf16 else None
     q = torch.empty(x.shape, device=x.device, dtype=u8)
     dq = torch.empty(rows, device=x.device, dtype=f32)
+    rn = torch.empty(rows, device=x.device, dtype=f32) if want_rownorm else None
     with _Timed("ln_fwd_q8", 0.0, float(rows) * D * (3 + (2 if want_bf16 else 0)), f"{rows},{D}"):
-        lib.call("clipa_layernorm_fwd_q8", _p(x), _p(gamma), _p(beta), _p(y), _p(q), _p(dq), rows, D, float(eps), _stream())
-    return y, q, dq
+        lib.call("clipa_layernorm_fwd_q8n", _p(x), _p(gamma), _p(beta), _p(y), _p(q), _p(dq), _p(rn), rows, D, float(eps), _stream())
+    return (y, q, dq, rn) if want_rownorm else (y, q, dq)
 
 
 def _whole_tiles_f8(M, N, K):
@@ -216,12 +220,60 @@ def _whole_tiles_f8(M, N, K):
     return M % 256 == 0 and N % 256 == 0 and K % 256 == 0 and K >= 512
 
 
+def row_bound(rownorm, wnorm, bmax=None, factor=1.13):
+    """Predicted row scales of a GEMM output: bound[m] = factor * rownorm[m] * wnorm[0] + bmax[0] >= every |output| of row m
+    (Cauchy-Schwarz; factor 1.13 covers the e4m3 rounding of both operands) -> (scale = bound / 448, inv = 448 / bound), f32 [M]."""
+    _chk(rownorm, f32, "rownorm", 1)
+    _chk(wnorm, f32, "wnorm", 1)
+    if bmax is not None:
+        _chk(bmax, f32, "bmax", 1)
+    M = rownorm.numel()
+    scale = torch.empty(M, device=rownorm.device, dtype=f32)
+    inv = torch.empty(M, device=rownorm.device, dtype=f32)
+    lib.call("clipa_row_bound", _p(rownorm.contiguous()), _p(wnorm), _p(bmax), float(factor), _p(scale), _p(inv), M, _stream())
+    return scale, inv
+
+
+def rownorm_max(w):
+    """f32 device scalar [1] = max_r ||w[r,:]||_2 of a bf16 matrix (a weight operand: once per optimizer step)."""
+    _chk(w, bf16, "w", 2)
+    w, ld = _rowmajor(w)
+    out = torch.empty(1, device=w.device, dtype=f32)
+    lib.call("clipa_rownorm_max", _p(w), w.shape[0], w.shape[1], ld, _p(out), _stream())
+    return out
+
+
+def absmax(v):
+    """f32 device scalar [1] = max |v[i]| of an f32 vector (a bias)."""
+    _chk(v, f32, "v", 1)
+    out = torch.empty(1, device=v.device, dtype=f32)
+    lib.call("clipa_absmax_f32", _p(v.contiguous()), v.numel(), _p(out), _stream())
+    return out
+
+
 def gemm_nt_f8(a8, sa, b8, sb, bias=None, *, epi=EPI_NONE, act=ACT_GELU_ERF, aux=None, alpha=1.0, want_pre=False,
-               fmt_a=FMT_E4M3, fmt_b=FMT_E4M3):
+               fmt_a=FMT_E4M3, fmt_b=FMT_E4M3, out_scale=None, want_colsum=False):
     """C[M,N] bf16 = epi(alpha * sa[m] * sb[n] * a8[M,K] @ b8[N,K]^T + bias); a8, b8 uint8 tensors of fp8 bytes.
     want_pre: True -> also the bf16 pre-activation; "e4m3" -> it as saturating e4m3 bytes (uint8 [M,N]: fused into the epilogue on
-    whole-tile shapes, GEMM + cast otherwise).  aux of EPI_DACT may be such a uint8 tensor."""
+    whole-tile shapes, GEMM + cast otherwise).  aux of EPI_DACT may be such a uint8 tensor.
+    out_scale (f32 [M]; round 6): the output leaves as e4m3 bytes, row m = the bf16 result times out_scale[m] (the operand of the
+    next GEMM with de-quantisation scale 1 / out_scale: row_bound) - written by the epilogue itself for EPI_ACT and for EPI_DACT
+    from an e4m3 operand on whole-tile shapes, GEMM + scaled quantiser otherwise; want_colsum (EPI_DACT): also the column sums of
+    the unscaled outputs (f32 [N]).  -> q8 [, pre] [, colsum]."""
     whole = _whole_tiles_f8(a8.shape[0], b8.shape[0], a8.shape[1]) and fmt_b == FMT_E4M3
+    if out_scale is not None:
+        fused = whole and ((epi == EPI_ACT and not want_colsum) or (epi == EPI_DACT and aux is not None and aux.dtype == u8 and bias is None))
+        if not fused:
+            r = gemm_nt_f8(a8, sa, b8, sb, bias, epi=epi, act=act, aux=aux, alpha=alpha, want_pre=want_pre, fmt_a=fmt_a, fmt_b=fmt_b)
+            out, pre = r if want_pre else (r, None)
+            ones = torch.ones(1, device=out.device, dtype=f32)
+            res = [scale_quantize_rows(out, out_scale, ones)]
+            if want_pre:
+                res.append(pre)
+            if want_colsum:
+                res.append(colsum(out))
+            return res[0] if len(res) == 1 else tuple(res)
+        return _gemm_nt_f8q(a8, sa, b8, sb, bias, epi, act, aux, alpha, want_pre, fmt_a, out_scale, want_colsum)
     if want_pre == "e4m3" and not (epi == EPI_ACT and whole):
         o, pre = gemm_nt_f8(a8, sa, b8, sb, bias, epi=epi, act=act, aux=aux, alpha=alpha, want_pre=True, fmt_a=fmt_a, fmt_b=fmt_b)
         return o, cast_e4m3(pre)
@@ -265,6 +317,48 @@ def gemm_nt_f8(a8, sa, b8, sb, bias=None, *, epi=EPI_NONE, act=ACT_GELU_ERF, aux
         lib.call("clipa_gemm_nt_f8", _p(a8), _p(b8), _p(sa), _p(sb), _p(out), _p(pre), _p(bias), _p(aux), M, N, K, lda, ldb,
                  N, ldaux, float(alpha), epi, act, int(fmt_a), int(fmt_b), _stream())
     return (out, pre) if want_pre else out
+
+
+def _gemm_nt_f8q(a8, sa, b8, sb, bias, epi, act, aux, alpha, want_pre, fmt_a, out_scale, want_colsum):
+    """The fused form of gemm_nt_f8(out_scale=...) (clipa_gemm_nt_f8q; whole-tile shapes)."""
+    _chk(a8, u8, "a8", 2)
+    _chk(b8, u8, "b8", 2)
+    _chk(out_scale, f32, "out_scale", 1)
+    a8, lda = _rowmajor(a8)
+    b8, ldb = _rowmajor(b8)
+    M, K = a8.shape
+    N = b8.shape[0]
+    if out_scale.numel() != M:
+        raise RuntimeError(f"gemm_nt_f8: out_scale has {out_scale.numel()} entries for {M} rows")
+    for name, t, n in (("sa", sa, M), ("sb", sb, N)):
+        if t is not None:
+            _chk(t, f32, name, 1)
+            if t.numel() != n or not t.is_contiguous():
+                raise RuntimeError(f"gemm_nt_f8: {name} must be a contiguous f32 vector of {n} elements")
+    q = torch.empty((M, N), device=a8.device, dtype=u8)
+    pre8 = want_pre == "e4m3"
+    pre = torch.empty((M, N), device=a8.device, dtype=u8 if pre8 else bf16) if want_pre else None
+    ldaux, code, part = 0, epi, None
+    if epi == EPI_DACT:
+        _chk(aux, u8, "aux", 2)
+        aux, ldaux = _rowmajor(aux)
+        code = EPI_DACT8
+        part = torch.empty((M // 128, N), device=a8.device, dtype=f32)
+    elif pre8:
+        code = EPI_ACT_PRE8
+    nbytes = 1.0 * (M * K + N * K) + 1.0 * M * N + (1.0 * M * N if aux is not None else 0) + ((1.0 if pre8 else 2.0) * M * N if want_pre else 0)
+    tag = {EPI_ACT_PRE8: "1+pre8", EPI_DACT8: "3,aux8"}.get(code, f"{epi}{'+pre' if want_pre else ''}")
+    with _Timed("gemm_nt_f8", 2.0 * M * N * K, nbytes, f"{M},{N},{K},epi{tag},q8"):
+        lib.call("clipa_gemm_nt_f8q", _p(a8), _p(b8), _p(sa), _p(sb), _p(q), _p(pre), _p(bias), _p(aux), _p(out_scale.contiguous()),
+                 _p(part), M, N, K, lda, ldb, N, ldaux, float(alpha), code, act, int(fmt_a), _stream())
+    res = [q]
+    if want_pre:
+        res.append(pre)
+    if want_colsum:
+        cs = torch.empty(N, device=a8.device, dtype=f32)
+        lib.call("clipa_reduce_partial_rows", _p(part), _p(cs), M // 128, N, _stream())
+        res.append(cs)
+    return res[0] if len(res) == 1 else tuple(res)
 
 
 def rowscale_max(a, b=None):

@@ -86,6 +86,30 @@ int clipa_gemm_nt_f8(const void* A8, const void* B8, const float* scale_a, const
                      int64_t ldc, int64_t ldaux, float alpha, int epi, int act, int fmt_a, int fmt_b, void* stream);
 int clipa_layernorm_fwd_q8(const void* x, const float* gamma, const float* beta, void* y, void* q, float* dq,
                            int64_t rows, int64_t D, float eps, void* stream);
+/* Producer-fused quantisation (round 6): the fp8 operand of the next GEMM written by the kernel that produces it, with a row scale
+ * the caller PREDICTS (the row maximum is spread over a row's N tiles): |sum_k a[m,k] w[n,k]| <= ||a[m,:]|| * max_n ||w[n,:]||.
+ * clipa_layernorm_fwd_q8n: clipa_layernorm_fwd_q8 that also returns rownorm[r] = ||LayerNorm(x)[r,:]||_2 (bf16-rounded values).
+ * clipa_gemm_nt_f8q: clipa_gemm_nt_f8 whose output C8 is e4m3 bytes (row stride ldc BYTES): row m = the bf16-rounded result times
+ * scale_out[m], saturating at +-448.  epi: CLIPA_EPI_ACT (C2 NULL or the bf16 pre-activation copy), CLIPA_EPI_ACT_PRE8 (C2 = e4m3
+ * pre-activation copy), CLIPA_EPI_DACT8 (aux = e4m3 bytes; colsum_partial [M / 128][N] f32 receives per-128-row column sums of the
+ * UNSCALED outputs: the bias gradient after clipa_reduce_partial_rows).  Whole-tile shapes, e4m3 weights; bit-identical to
+ * clipa_gemm_nt_f8 followed by clipa_scale_quantize_rows(out, scale_out, t = 1).
+ * clipa_reduce_partial_rows: out[k] = sum_r partial[r][k] in a fixed order (K % 4 == 0). */
+int clipa_layernorm_fwd_q8n(const void* x, const float* gamma, const float* beta, void* y, void* q, float* dq, float* rownorm,
+                            int64_t rows, int64_t D, float eps, void* stream);
+int clipa_gemm_nt_f8q(const void* A8, const void* B8, const float* scale_a, const float* scale_b, void* C8, void* C2,
+                      const float* bias, const void* aux, const float* scale_out, float* colsum_partial, int64_t M, int64_t N,
+                      int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldaux, float alpha, int epi, int act, int fmt_a,
+                      void* stream);
+int clipa_reduce_partial_rows(const float* partial, float* out, int64_t nrows, int64_t K, void* stream);
+/* The predicted row scales themselves: clipa_rownorm_max: out[0] = max_r ||w[r,:]||_2 (w bf16 [rows, K], row stride ld);
+ * clipa_absmax_f32: out[0] = max |v[i]|; clipa_row_bound: bound = factor * rownorm[m] * wnorm[0] + bmax[0] (bmax NULL = 0) ->
+ * scale[m] = bound / 448 (the row's de-quantisation scale), inv[m] = 448 / bound (its clipa_gemm_nt_f8q scale_out); both 0 for a
+ * zero row.  wnorm / bmax are device scalars, computed once per optimizer step. */
+int clipa_rownorm_max(const void* w, int64_t rows, int64_t K, int64_t ld, float* out, void* stream);
+int clipa_absmax_f32(const float* v, int64_t n, float* out, void* stream);
+int clipa_row_bound(const float* rownorm, const float* wnorm_dev, const float* bmax_dev, float factor, float* scale, float* inv,
+                    int64_t n, void* stream);
 
 /* fp8 WEIGHT gradients (round 6; same call sites as clipa_gemm_tn: the autograd transposes of nn.Linear / in-proj / out-proj,
  * transformer.py:209,217-219,234).  The reduction of dW = dY^T . X runs over tokens, so a per-token scale cannot be factored out:
@@ -103,10 +127,10 @@ int clipa_layernorm_fwd_q8(const void* x, const float* gamma, const float* beta,
  * four-wave kernel of gemm_tn8.hip; rows beyond its slices, and every other shape, on a byte-gather kernel. */
 /* clipa_quantize_rows_colsum: clipa_quantize_rows that also returns colsum[k] = sum_r x[r,k] (f32 [K]) - the bias gradient of the
  * layer (the column sums of dY: nn.Linear's bias, transformer.py:209,217-219) from the pass that quantises dY for the input-gradient
- * and weight-gradient GEMMs; fixed summation order.  workspace: per-block partial rows. */
+ * and weight-gradient GEMMs; fixed summation order; rownorm (optional, f32 [rows]) = ||x[r,:]||_2.  workspace: per-block partial rows. */
 int64_t clipa_quantize_rows_colsum_workspace(int64_t rows, int64_t K);
-int clipa_quantize_rows_colsum(const void* x, void* q, float* dq, float* colsum, int64_t rows, int64_t K, int64_t ldx, int64_t ldq,
-                               int fmt, void* workspace, int64_t workspace_bytes, void* stream);
+int clipa_quantize_rows_colsum(const void* x, void* q, float* dq, float* colsum, float* rownorm, int64_t rows, int64_t K, int64_t ldx,
+                               int64_t ldq, int fmt, void* workspace, int64_t workspace_bytes, void* stream);
 int clipa_rowscale_max(const float* a, const float* b, int64_t n, float* out, void* stream);
 int clipa_scale_quantize_rows(const void* x, const float* rowscale, const float* t_dev, void* q, int64_t rows, int64_t K,
                               int64_t ldx, int64_t ldq, int act, void* stream);

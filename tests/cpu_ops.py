@@ -58,14 +58,29 @@ u8 = torch.uint8
 _F8 = {0: (torch.float8_e4m3fn, 448.0), 1: (torch.float8_e5m2, 57344.0)}
 
 
-def quantize_rows(x, fmt=FMT_E4M3, want_colsum=False):
+def quantize_rows(x, fmt=FMT_E4M3, want_colsum=False, want_rownorm=False):
     dt, fmax = _F8[fmt]
     xf = x.float()
     amax = xf.abs().amax(dim=1)
     s = torch.where(amax > 0, fmax / amax, torch.ones_like(amax))
     dq = torch.where(amax > 0, amax / fmax, torch.zeros_like(amax))
     q = (xf * s[:, None]).to(dt).view(u8)
+    if want_colsum and want_rownorm:
+        return q, dq, xf.sum(0), xf.norm(dim=1)
     return (q, dq, xf.sum(0)) if want_colsum else (q, dq)
+
+
+def row_bound(rownorm, wnorm, bmax=None, factor=1.13):
+    b = factor * rownorm * wnorm + (bmax if bmax is not None else 0.0)
+    return torch.where(b > 0, b / 448.0, torch.zeros_like(b)), torch.where(b > 0, 448.0 / b, torch.zeros_like(b))
+
+
+def rownorm_max(w):
+    return w.float().norm(dim=1).max().reshape(1)
+
+
+def absmax(v):
+    return v.float().abs().max().reshape(1)
 
 
 def rowscale_max(a, b=None):
@@ -90,17 +105,27 @@ def gemm_tn_f8(p8, q8, t=None, alpha=1.0, fmt_p=FMT_E4M3, out_dtype=f32):
     return (v * (alpha * (float(t) if t is not None else 1.0))).to(out_dtype)
 
 
-def layernorm_fwd_q8(x, gamma, beta, eps=1e-5, want_bf16=False):
+def layernorm_fwd_q8(x, gamma, beta, eps=1e-5, want_bf16=False, want_rownorm=False):
     y = layernorm_fwd(x, gamma, beta, eps)
     q, dq = quantize_rows(y.reshape(-1, y.shape[-1]))
-    return (y if want_bf16 else None), q.reshape(y.shape), dq
+    r = ((y if want_bf16 else None), q.reshape(y.shape), dq)
+    return r + (y.reshape(-1, y.shape[-1]).float().norm(dim=1),) if want_rownorm else r
 
 
 def gemm_nt_f8(a8, sa, b8, sb, bias=None, *, epi=EPI_NONE, act=0, aux=None, alpha=1.0, want_pre=False, fmt_a=FMT_E4M3,
-               fmt_b=FMT_E4M3):
+               fmt_b=FMT_E4M3, out_scale=None, want_colsum=False):
     a = a8.view(_F8[fmt_a][0]).float() * (sa[:, None] if sa is not None else 1.0)
     b = b8.view(_F8[fmt_b][0]).float() * (sb[:, None] if sb is not None else 1.0)
-    return gemm_nt(a, b, bias, epi=epi, act=act, aux=aux, alpha=alpha, want_pre=want_pre)
+    r = gemm_nt(a, b, bias, epi=epi, act=act, aux=aux, alpha=alpha, want_pre=want_pre)
+    if out_scale is None:
+        return r
+    out, pre = r if want_pre else (r, None)
+    res = [_e4m3(out.float() * out_scale[:, None])]
+    if want_pre:
+        res.append(pre)
+    if want_colsum:
+        res.append(out.float().sum(0))
+    return res[0] if len(res) == 1 else tuple(res)
 
 
 def gemm_tn(p, q, out_dtype=f32, want_colsum=False):

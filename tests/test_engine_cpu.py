@@ -23,14 +23,14 @@ def _swap_ops(monkeypatch):
         monkeypatch.setattr(mod, "ops", cpu_ops)
 
 
-def _run(g, recompute=True, precision="fp32", tiers=None, grad_fmt="e4m3"):
+def _run(g, recompute=True, precision="fp32", tiers=None, grad_fmt="e4m3", predict=False):
     m = clipa_amd.CLIP(**g.cfg, output_dict=True)
     m.load_state_dict(g.sd, strict=True)
     if precision in ("bf16", "fp8"):
         clipa_amd.convert_weights_to_lp(m, torch.bfloat16)
     if precision == "fp8":
         for t in (m.visual.transformer, m.transformer):
-            t.fp8, t.fp8_grad_format = True, grad_fmt
+            t.fp8, t.fp8_grad_format, t.fp8_predicted_scales = True, grad_fmt, predict
     m.set_grad_checkpointing(recompute)
     if tiers:
         for t in (m.visual.transformer, m.transformer):
@@ -256,6 +256,21 @@ def test_fp8_orchestration(golden):
             assert torch.equal(p.grad, q.grad) and torch.equal(p.grad, r.grad), k
     me, _, le = _run(g, precision="fp8", grad_fmt="e5m2")
     assert abs(float(le) - float(g.t("loss"))) < 4e-2 * float(g.t("loss"))
+    # the predicted-row-scale knob (round 6): same tolerances, and the same bit-for-bit equality between the tiers
+    mp, outp, lp = _run(g, precision="fp8", predict=True)
+    assert (outp["image_features"].float() - g.t("image_features")).abs().max() < 6e-2
+    assert abs(float(lp) - float(g.t("loss"))) < 4e-2 * float(g.t("loss"))
+    for k, p in mp.named_parameters():
+        if p.grad is None or p.grad.numel() == 1 or float(ref[k].float().norm()) < 1e-7:
+            continue
+        a, b = p.grad.double().reshape(-1), ref[k].double().reshape(-1)
+        assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.95, k
+    mq, _, lq = _run(g, precision="fp8", recompute=False, predict=True)
+    mr, _, lr = _run(g, precision="fp8", recompute=True, tiers=(1, 1), predict=True)
+    assert float(lp) == float(lq) == float(lr)
+    for (k, p), (_, q), (_, r) in zip(mp.named_parameters(), mq.named_parameters(), mr.named_parameters()):
+        if p.grad is not None:
+            assert torch.equal(p.grad, q.grad) and torch.equal(p.grad, r.grad), k
 
 
 def test_optimizer_step_refreshes_weight_cache_and_reduces_loss():

@@ -234,13 +234,13 @@ import clipa_amd  # noqa: E402
 from .conftest import load_golden  # noqa: E402
 
 
-def _fp8_engine(g, recompute=True, grad_fmt="e4m3"):
+def _fp8_engine(g, recompute=True, grad_fmt="e4m3", predict=False):
     m = clipa_amd.CLIP(**g.cfg, output_dict=True)
     m.load_state_dict(g.sd, strict=True)
     m.to(DEV)
     clipa_amd.convert_weights_to_lp(m, torch.bfloat16)
     for t in (m.visual.transformer, m.transformer):
-        t.fp8, t.fp8_grad_format = True, grad_fmt
+        t.fp8, t.fp8_grad_format, t.fp8_predicted_scales = True, grad_fmt, predict
     m.set_grad_checkpointing(recompute)
     return m
 
@@ -262,8 +262,8 @@ def _oracle_grads(g):
     return {k: v.grad for k, v in sd.items() if v.grad is not None}
 
 
-def _check_fp8_model(g, feat_tol, loss_tol, cos_min, cos_median, norm_tol):
-    m = _fp8_engine(g)
+def _check_fp8_model(g, feat_tol, loss_tol, cos_min, cos_median, norm_tol, predict=False):
+    m = _fp8_engine(g, predict=predict)
     out, loss = _fp8_step(m, g)
     i, t = out["image_features"].float().cpu(), out["text_features"].float().cpu()
     fi, ft = (i - g.t("image_features")).abs().max().item(), (t - g.t("text_features")).abs().max().item()
@@ -279,9 +279,11 @@ def _check_fp8_model(g, feat_tol, loss_tol, cos_min, cos_median, norm_tol):
             continue
         coss.append((float(torch.dot(a, b) / (a.norm() * b.norm())), k))
         ratios.append(float(a.norm() / b.norm()))
+        if abs(ratios[-1] - 1.0) > 0.15:
+            print(f"[fp8 {g.name}] norm ratio {ratios[-1]:.3f} cosine {coss[-1][0]:.4f} |ref| {float(b.norm()):.3e}: {k}")
     coss.sort()
     med = coss[len(coss) // 2][0]
-    print(f"[fp8 {g.name}] feature err {fi:.4f} / {ft:.4f}, loss rel {lrel:.4f}, gradient cosine min {coss[0][0]:.4f} "
+    print(f"[fp8{' predicted scales' if predict else ''} {g.name}] feature err {fi:.4f} / {ft:.4f}, loss rel {lrel:.4f}, gradient cosine min {coss[0][0]:.4f} "
           f"({coss[0][1]}) median {med:.4f}, norm ratio {min(ratios):.3f}..{max(ratios):.3f}")
     assert fi < feat_tol and ft < feat_tol
     assert lrel < loss_tol
@@ -301,6 +303,30 @@ def test_fp8_full_dims_match_reference_golden(golden_full):
     0.81..1.15), with a margin; what that accuracy means for training is the convergence A/B of
     profiles/r03_fp8_convergence_S16_112.jsonl."""
     _check_fp8_model(golden_full, 4e-2, 0.02, 0.89, 0.94, 0.22)
+
+
+def test_fp8_predicted_row_scales_full_dims(golden_full):
+    """The engine knob fp8_predicted_scales (round 6; off by default): the MLP's 4 D-wide tensors leave their GEMMs as e4m3 operands with
+    Cauchy-Schwarz row scales.  Measured against the fp32 reference fixtures (profiles/r06_pytest_fp8_parity.log): gradient cosine min
+    0.898-0.927 (0.901-0.931 with the rows' true maxima), median 0.944-0.952 (0.947-0.954); the vectors that are sums over the batch of
+    the pooled rows' gradients (last blocks' biases, the heads' LayerNorm bias) move by up to 30 % in norm at these batches of 2-4."""
+    _check_fp8_model(golden_full, 4e-2, 0.02, 0.88, 0.935, 0.33, predict=True)
+
+
+def test_fp8_predicted_row_scales_tiers_are_bit_identical():
+    g = load_golden("cls_erf")
+    ga = {}
+    for rc in (True, False, "mixed"):
+        m = _fp8_engine(g, recompute=bool(rc), predict=True)
+        if rc == "mixed":
+            for t in (m.visual.transformer, m.transformer):
+                t.keep_blocks, t.medium_blocks = 1, 1
+        _, loss = _fp8_step(m, g)
+        ga[rc] = (float(loss), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert ga[True][0] == ga[False][0] == ga["mixed"][0]
+    for k in ga[True][1]:
+        assert torch.equal(ga[True][1][k], ga[False][1][k]), k
+        assert torch.equal(ga[True][1][k], ga["mixed"][1][k]), k
 
 
 def test_fp8_recompute_equals_stored_activations():
@@ -503,3 +529,88 @@ def test_fp8_per_tensor_keep_sets(name):
         worst = min(worst, float(torch.dot(a, b) / (a.norm() * b.norm())))
     print(f"[fp8 h8 tier, {name}] worst gradient cosine against the recomputed step {worst:.4f}")
     assert worst > 0.99
+
+
+# ---- producer-fused quantisation with predicted row scales (round 6) --------------------------------------------------------
+def test_row_bound_helpers():
+    """rownorm_max / absmax / row_bound and the row norms the quantising kernels return: plain fp32 arithmetic against torch."""
+    o = ops()
+    g = torch.Generator().manual_seed(3)
+    w = (torch.randn(520, 1280, generator=g) * 0.03).to(bf16)
+    b = torch.randn(520, generator=g)
+    assert abs(o.rownorm_max(w.to(DEV)).item() - w.float().norm(dim=1).max().item()) < 1e-5 * w.float().norm(dim=1).max().item()
+    assert o.absmax(b.to(DEV)).item() == b.abs().max().item()
+    x = (torch.randn(300, 1280, generator=g) * torch.exp(torch.randn(300, 1, generator=g))).to(bf16)
+    x[7] = 0
+    q, dq, cs, rn = o.quantize_rows(x.to(DEV), want_colsum=True, want_rownorm=True)
+    torch.testing.assert_close(rn.cpu(), x.float().norm(dim=1), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(cs.cpu(), x.float().sum(0), rtol=1e-4, atol=1e-3)
+    q2, dq2 = o.quantize_rows(x.to(DEV))
+    assert torch.equal(q, q2) and torch.equal(dq, dq2)
+    gam, bet = rnd(1280, seed=1, dtype=f32).to(DEV) + 1.0, rnd(1280, seed=2, dtype=f32).to(DEV)
+    y, qy, sy, rny = o.layernorm_fwd_q8(x.to(DEV), gam, bet, want_bf16=True, want_rownorm=True)
+    torch.testing.assert_close(rny.cpu(), y.float().norm(dim=1).cpu(), rtol=1e-5, atol=1e-6)
+    wn, bm = o.rownorm_max(w.to(DEV)), o.absmax(b.to(DEV))
+    sc, inv = o.row_bound(rn, wn, bm, 1.13)
+    bound = 1.13 * x.float().norm(dim=1) * wn.item() + bm.item()
+    torch.testing.assert_close(sc.cpu(), bound / 448.0, rtol=1e-5, atol=0)
+    torch.testing.assert_close(inv.cpu(), 448.0 / bound, rtol=1e-5, atol=0)
+    sc0, inv0 = o.row_bound(rn, wn, None, 1.0)
+    assert sc0[7].item() == 0.0 and inv0[7].item() == 0.0             # a zero row: zero scale, zero multiplier
+
+
+@pytest.mark.parametrize("act", [0, 2])
+def test_gemm_f8a_producer_quantised_outputs(act):
+    """clipa_gemm_nt_f8q: the epilogue writing the next GEMM's e4m3 operand with a caller-predicted row scale is bit-identical to the
+    GEMM followed by the scaled quantiser (activation, with and without either pre-activation copy; GELU-backward from e4m3 bytes);
+    the fused column sums are the sums of the bf16-rounded outputs; the Cauchy-Schwarz scale never saturates and the de-quantised
+    bytes are the bf16 outputs to e4m3 precision."""
+    o = ops()
+    from clipa_amd import lib
+    M, N, K = 768, 1024, 512
+    x = rnd(M, K, seed=41) * torch.exp(rnd(M, 1, seed=42, dtype=f32) * 0.5)
+    w = rnd(N, K, seed=43, scale=0.04)
+    bias = rnd(N, seed=44, dtype=f32) * 0.1
+    X, W, BIAS = x.to(bf16).to(DEV), w.to(bf16).to(DEV), bias.to(DEV)
+    xq, xs, _, rn = o.quantize_rows(X, want_colsum=True, want_rownorm=True)
+    wq, ws = o.quantize_rows(W)
+    sc, inv = o.row_bound(rn, o.rownorm_max(W), o.absmax(BIAS), 1.13)
+    one = torch.ones(1, device=DEV)
+    for want_pre in (False, True, "e4m3"):
+        lib.gemm_counts(reset=True)
+        r = o.gemm_nt_f8(xq, xs, wq, ws, BIAS, epi=o.EPI_ACT, act=act, want_pre=want_pre, out_scale=inv)
+        assert lib.gemm_counts()[14] == 1, "the producer-quantised epilogue did not run"
+        ref = o.gemm_nt_f8(xq, xs, wq, ws, BIAS, epi=o.EPI_ACT, act=act, want_pre=want_pre)
+        (q8, pre), (out, pre_ref) = (r if want_pre else (r, None)), (ref if want_pre else (ref, None))
+        assert torch.equal(q8, o.scale_quantize_rows(out, inv, one)), want_pre
+        if want_pre:
+            assert torch.equal(pre, pre_ref)
+        deq = q8.view(torch.float8_e4m3fn).float() * sc[:, None]
+        assert q8.view(torch.float8_e4m3fn).float().abs().max().item() < 448.0, "the predicted scale saturated"
+        err = (deq - out.float()).abs()
+        assert (err <= 2.0 ** -4 * out.float().abs() + sc[:, None] * 2.0 ** -9).all()
+    # GELU-backward from the e4m3 pre-activation, gradient rows of very different size, + column sums
+    _, pre8 = o.gemm_nt_f8(xq, xs, wq, ws, BIAS, epi=o.EPI_ACT, act=act, want_pre="e4m3")
+    dy = (rnd(M, 256, seed=45) * torch.exp(rnd(M, 1, seed=46, dtype=f32) * 2.0) * 1e-3).to(bf16).to(DEV)
+    dy[5] = 0
+    wt = rnd(N, 256, seed=47, scale=0.04).to(bf16).to(DEV)
+    dq, ds, _, rnd_y = o.quantize_rows(dy, want_colsum=True, want_rownorm=True)
+    wtq, wts = o.quantize_rows(wt)
+    sdh, sodh = o.row_bound(rnd_y, o.rownorm_max(wt), None, 1.13 * 1.13)
+    # K = 256 is below the four-wave kernel's minimum: pad the reduction to 512 with zeros (same product)
+    pad = lambda t: torch.cat([t, torch.zeros_like(t)], dim=1).contiguous()
+    lib.gemm_counts(reset=True)
+    q8, cs = o.gemm_nt_f8(pad(dq), ds, pad(wtq), wts, epi=o.EPI_DACT, act=act, aux=pre8, out_scale=sodh, want_colsum=True)
+    assert lib.gemm_counts()[14] == 1
+    dh = o.gemm_nt_f8(pad(dq), ds, pad(wtq), wts, epi=o.EPI_DACT, act=act, aux=pre8)
+    assert torch.equal(q8, o.scale_quantize_rows(dh, sodh, one))
+    torch.testing.assert_close(cs, dh.float().sum(0), rtol=2e-4, atol=1e-6 * dh.float().abs().sum(0).max().item())
+    assert (q8[5].view(torch.float8_e4m3fn).float() == 0).all() and q8.view(torch.float8_e4m3fn).float().abs().max().item() < 448.0
+    # ragged shapes compose GEMM + scaled quantiser (+ column sums) with the same arithmetic
+    xr = rnd(300, 272, seed=48).to(bf16).to(DEV)
+    wr = rnd(264, 272, seed=49, scale=0.05).to(bf16).to(DEV)
+    xrq, xrs, _, rnr = o.quantize_rows(xr, want_colsum=True, want_rownorm=True)
+    wrq, wrs = o.quantize_rows(wr)
+    scr, invr = o.row_bound(rnr, o.rownorm_max(wr), None, 1.13)
+    qr = o.gemm_nt_f8(xrq, xrs, wrq, wrs, epi=o.EPI_ACT, act=act, out_scale=invr)
+    assert torch.equal(qr, o.scale_quantize_rows(o.gemm_nt_f8(xrq, xrs, wrq, wrs, epi=o.EPI_ACT, act=act), invr, one))
