@@ -54,6 +54,9 @@ def run_engine(precision, grad_fmt, args, base, toks, length, cfg):
     dev = torch.device("cuda", 0)
     torch.manual_seed(args.seed)
     m = clipa_amd.CLIP(**cfg, output_dict=True).to(dev)
+    pred = precision == "fp8_h8_pred"
+    if pred:
+        precision = "fp8_h8"
     h8 = precision in ("bf16_h8", "fp8_h8")
     if h8:
         precision = precision[:-3]
@@ -64,7 +67,7 @@ def run_engine(precision, grad_fmt, args, base, toks, length, cfg):
             t.keep_counts = dict(t.keep_counts, h8=t.layers, a=t.layers, x1=t.layers)
     if precision == "fp8":
         for t in (m.visual.transformer, m.transformer):
-            t.fp8, t.fp8_grad_format = True, grad_fmt
+            t.fp8, t.fp8_grad_format, t.fp8_predicted_scales = True, grad_fmt, pred
     m.set_grad_checkpointing(True)
     named = list(m.named_parameters())
     exclude = lambda n, p: p.ndim < 2 or "bn" in n or "ln" in n or "bias" in n or "logit_scale" in n
@@ -127,7 +130,7 @@ def main():
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--oracle-steps", type=int, default=12)
-    ap.add_argument("--arms", default="bf16,fp8_e4m3_grad,fp8_e5m2_grad", help="comma-separated: bf16, bf16_h8, fp8_e4m3_grad, fp8_e5m2_grad, fp8_h8 (round 6: every arm with fp8 weight gradients; fp8_h8 = bench.py's fp8 plan, the e4m3 pre-activation kept in every block)")
+    ap.add_argument("--arms", default="bf16,fp8_e4m3_grad,fp8_e5m2_grad", help="comma-separated: bf16, bf16_h8, fp8_e4m3_grad, fp8_e5m2_grad, fp8_h8, fp8_h8_pred (round 6: every fp8 arm with fp8 weight gradients; fp8_h8 = bench.py's fp8 plan, the e4m3 pre-activation kept in every block; _pred = + the predicted-row-scale knob)")
     args = ap.parse_args()
     import clipa_amd
     cfg = clipa_amd.get_model_config("ViT-S-16")
@@ -136,7 +139,7 @@ def main():
     base, toks, length = make_data(args.concepts, 112, 32, cfg["text_cfg"]["vocab_size"], 42)
     runs = {}
     ARMS = {"bf16": ("bf16", None), "bf16_h8": ("bf16_h8", None), "fp8_e4m3_grad": ("fp8", "e4m3"), "fp8_e5m2_grad": ("fp8", "e5m2"),
-            "fp8_h8": ("fp8_h8", "e4m3")}
+            "fp8_h8": ("fp8_h8", "e4m3"), "fp8_h8_pred": ("fp8_h8_pred", "e4m3")}
     for name in args.arms.split(","):
         prec, fmt = ARMS[name]
         runs[name] = run_engine(prec, fmt, args, base, toks, length, cfg)
