@@ -718,39 +718,10 @@ __global__ void e4m3_to_bf16_kernel(const unsigned char* __restrict__ in, unsign
     st_stream<u32x4>(out + 8 * i, pack8(f));
   }
 }
-// The same re-materialisation through a table (round 6): an e4m3 byte has 256 values, so bf16(act(x)) is a 256-entry table in LDS
-// (built per block by its 256 threads with the arithmetic of the kernel above: bit-identical outputs) and an element costs one
-// LDS gather instead of ~14 VALU instructions - the polynomial version is VALU-bound (1.7 T elements/s), this one streams.
-// 16 elements per thread: one 16-byte load, two 16-byte stores.
-#ifndef ACT_E4M3_LUT
-#define ACT_E4M3_LUT 1                             // A/B knob: 0 keeps the polynomial kernel
-#endif
-__global__ __launch_bounds__(256) void e4m3_act_lut_kernel(const unsigned char* __restrict__ in, unsigned short* __restrict__ out, long n16, int act) {
-  __shared__ unsigned lut[256];
-  {
-    float f[8];
-    u32x2 code;
-    code[0] = threadIdx.x;
-    code[1] = 0u;
-    e4m3x8_to_f32(code, f);
-    const f32x2 x = {f[0], f[0]};
-    const f32x2 r = act == ACT_GELU_ERF ? act_fwd2<ACT_GELU_ERF>(x) : (act == ACT_GELU_TANH ? act_fwd2<ACT_GELU_TANH>(x) : act_fwd2<ACT_QUICK_GELU>(x));
-    lut[threadIdx.x] = (unsigned)f2bf(r.x);
-  }
-  __syncthreads();
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n16) return;
-  const u32x4 q = ld_stream<u32x4>(in + 16 * i);
-  u32x4 lo, hi;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const unsigned c = q[w];
-    const unsigned a = lut[c & 255u] | (lut[(c >> 8) & 255u] << 16), b = lut[(c >> 16) & 255u] | (lut[c >> 24] << 16);
-    if (w < 2) { lo[2 * w] = a; lo[2 * w + 1] = b; } else { hi[2 * (w - 2)] = a; hi[2 * (w - 2) + 1] = b; }
-  }
-  st_stream<u32x4>(out + 16 * i, lo);
-  st_stream<u32x4>(out + 16 * i + 8, hi);
-}
+// A table-driven variant (256-entry bf16 table in LDS, 16 gathers per 16-byte load) was measured in round 6 and is NOT kept:
+// 2.30-2.52 ms against 1.81 ms for the kernel above on 806912 x 4096 bytes (profiles/r06_stream_kernels_activation_e4m3_lut_ab.jsonl).
+// With two output bytes per input byte the polynomial kernel already streams (5.4 TB/s) and the LDS gathers become the limit;
+// the table only pays where the per-element arithmetic is heavier (the e4m3 GELU emission and the gemm_nta DACT8 epilogue).
 // one-shot: a thread per 8 elements (a persistent grid striding the array streams a third slower, tools/probes/stream_ab.hip)
 unsigned cast_grid(long n8) { const long b = (n8 + 255) / 256; return (unsigned)(b < 1 ? 1 : (b > 0x7fffffffL ? 0x7fffffffL : b)); }
 int cast_args(const char* what, const void* in, const void* out, int64_t n) {
@@ -775,9 +746,6 @@ extern "C" int clipa_activation_fwd_e4m3(const void* x8, void* out, int64_t n, i
   if (n <= 0) return CLIPA_OK;
   if (int rc = cast_args("activation_fwd_e4m3", x8, out, n)) return rc;
   if (act < ACT_GELU_ERF || act > ACT_QUICK_GELU) { clipa_set_error("activation_fwd_e4m3: unknown activation %d", act); return CLIPA_ERR_ARG; }
-  if (ACT_E4M3_LUT && n % 16 == 0 && (((size_t)x8 | (size_t)out) & 15) == 0)
-    hipLaunchKernelGGL(e4m3_act_lut_kernel, dim3(cast_grid(n / 16)), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)x8, (unsigned short*)out, (long)(n / 16), act);
-  else
-    hipLaunchKernelGGL(e4m3_to_bf16_kernel<true>, dim3(cast_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)x8, (unsigned short*)out, (long)(n / 8), act);
+  hipLaunchKernelGGL(e4m3_to_bf16_kernel<true>, dim3(cast_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)x8, (unsigned short*)out, (long)(n / 8), act);
   return clipa_check_launch("activation_fwd_e4m3");
 }

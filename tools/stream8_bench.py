@@ -61,6 +61,7 @@ cases = {
     "scale_quantize_rows_D": (lambda: ops.scale_quantize_rows(x, ds, t), 3 * M * D),
     "scale_quantize_rows_4D_gelu": (lambda: ops.scale_quantize_rows(h, ds, t, act=0), 12 * M * D),
     "scale_quantize_rows_4D_gelu_in8": (lambda: ops.scale_quantize_rows(h8, ds, t, act=0), 8 * M * D),
+    "activation_fwd_e4m3_4D": (lambda: ops.activation_fwd(h8, 0), 12 * M * D),
     "ln_fwd_q8": (lambda: ops.layernorm_fwd_q8(x, gam, bet), 3 * M * D),
     "ln_fwd_q8s": (lambda: ops.layernorm_fwd_q8s(x, gam, bet, ds, t), 3 * M * D),
     "ln_fwd": (lambda: ops.layernorm_fwd(x, gam, bet), 4 * M * D),
