@@ -629,6 +629,7 @@ def main():
             final_budget -= 12 << 30
             keep_v, keep_t, med_v, med_t = plan(final_budget)
             set_keep(int(keep_v), int(keep_t), int(med_v), int(med_t))
+    reserved_timed = torch.cuda.max_memory_reserved(dev)
     retries_timed = int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0))     # through the timed region (the extra regions
     gather_wait_ms = loss_mod.wait_timing_stop() / args.steps if dist_on else 0.0      # below re-shape the allocator's segments)
     last_loss = float(loss)
@@ -654,6 +655,45 @@ def main():
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             ep = float(tm)
         plain_ms = round(1e3 * ep / args.plain_steps, 2)
+
+    # PCIe-inclusive rate (SURVEY 8d: the reference's batch_time includes the H2D copy, train.py:187-189): the same step
+    # fed from pinned host memory with staged uint8 NHWC images through DevicePrefetcher (copy stream, double buffered) +
+    # the on-device RandomResizedCrop / ColorJitter / Grayscale of the reference GPU recipe (scripts/exp/gpu/vit_l16/i37_t8_pretrain.sh:13).
+    # Never part of `value`.  Runs first among the extra regions: the allocator is still in the timed region's state (behind the
+    # exact-tier region, which re-shapes the segments under another plan, it ran into allocator retries: 1298 instead of 2440 pairs/s).
+    h2d = None
+    if args.h2d_steps > 0:
+        try:
+            from clipa_amd.data import DeviceAugment, DevicePrefetcher
+            stage = (args.image_size * 8 // 7 + 15) // 16 * 16                  # 224 -> 256, 84 -> 96
+            gh = torch.Generator().manual_seed(99 + rank)
+            base = torch.randint(0, 256, (64, stage, stage, 3), generator=gh, dtype=torch.uint8)
+            pool = [base.roll(k, 0).repeat((B + 63) // 64, 1, 1, 1)[:B].contiguous().pin_memory() for k in range(2)]
+            texts_host = texts.cpu().pin_memory()
+            n_h2d = args.h2d_steps
+            loader = ((pool[i % 2], texts_host) for i in range(n_h2d + 1))
+            aug = DeviceAugment(args.image_size, scale=(0.4, 1.0), color_jitter=(0.32, 0.32, 0.32, 0.08), color_jitter_prob=0.8,
+                                gray_scale_prob=0.2, seed=7 + rank)
+            feed = iter(DevicePrefetcher(loader, dev, transform=aug, depth=2))
+            step(*next(feed))                                                    # warm-up of the pipeline itself
+            fence()
+            th = time.perf_counter()
+            for _ in range(n_h2d):
+                loss_h = step(*next(feed))
+            fence()
+            eh = time.perf_counter() - th
+            if dist_on:
+                tm = torch.tensor([eh], device=dev, dtype=torch.float64)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                eh = float(tm)
+            ops.check_token_ids(wait=True)
+            h2d = {"value": round(B * world * n_h2d / eh, 2), "unit": "pairs/s", "ms_per_step": round(1e3 * eh / n_h2d, 2),
+                   "steps": n_h2d, "loss": round(float(loss_h), 4),
+                   "input": f"uint8 NHWC {stage}x{stage} staged images in pinned host memory -> DevicePrefetcher (depth 2, copy "
+                            f"stream) -> on-device RandomResizedCrop(scale 0.4-1, bicubic) + ColorJitter(0.32, 0.32, 0.32, 0.08; p=0.8) + Grayscale(p=0.2) -> {args.image_size} px"}
+            del pool, feed
+        except (RuntimeError, torch.OutOfMemoryError) as e:                      # the headline line must survive
+            h2d = {"value": None, "error": str(e)[:200]}
 
     # The same step under the keep plan restricted to BIT-EXACT tensors (no e4m3 pre-activation; VERDICT r4 next #1c): its
     # gradients are those of the all-recompute bf16 step bit for bit (tests/test_model_gpu.py::
@@ -691,7 +731,7 @@ def main():
     # part of `value`, which stays on the reference's schedule unless --unpad-text asks otherwise.
     unpad = None
     # Several ranks: toggling the knob changes the autograd graph, which DistributedDataParallel(static_graph=True) records in its
-    # first iteration - so this region (the LAST one that steps the model: it runs after the input-pipeline region below) drops the
+    # first iteration - so this region (the LAST one that steps the model) drops the
     # wrapper and wraps the model again with the knob set, as a trainer would set it before its wrap.
     def unpad_region():
         nonlocal step_model
@@ -727,44 +767,6 @@ def main():
         model.unpad_text = False
         return res
 
-    # PCIe-inclusive rate (SURVEY 8d: the reference's batch_time includes the H2D copy, train.py:187-189): the same step
-    # fed from pinned host memory with staged uint8 NHWC images through DevicePrefetcher (copy stream, double buffered) +
-    # the on-device RandomResizedCrop / ColorJitter / Grayscale of the reference GPU recipe (scripts/exp/gpu/vit_l16/i37_t8_pretrain.sh:13).
-    # Never part of `value`.
-    h2d = None
-    if args.h2d_steps > 0:
-        try:
-            from clipa_amd.data import DeviceAugment, DevicePrefetcher
-            stage = (args.image_size * 8 // 7 + 15) // 16 * 16                  # 224 -> 256, 84 -> 96
-            gh = torch.Generator().manual_seed(99 + rank)
-            base = torch.randint(0, 256, (64, stage, stage, 3), generator=gh, dtype=torch.uint8)
-            pool = [base.roll(k, 0).repeat((B + 63) // 64, 1, 1, 1)[:B].contiguous().pin_memory() for k in range(2)]
-            texts_host = texts.cpu().pin_memory()
-            n_h2d = args.h2d_steps
-            loader = ((pool[i % 2], texts_host) for i in range(n_h2d + 1))
-            aug = DeviceAugment(args.image_size, scale=(0.4, 1.0), color_jitter=(0.32, 0.32, 0.32, 0.08), color_jitter_prob=0.8,
-                                gray_scale_prob=0.2, seed=7 + rank)
-            feed = iter(DevicePrefetcher(loader, dev, transform=aug, depth=2))
-            step(*next(feed))                                                    # warm-up of the pipeline itself
-            fence()
-            th = time.perf_counter()
-            for _ in range(n_h2d):
-                loss_h = step(*next(feed))
-            fence()
-            eh = time.perf_counter() - th
-            if dist_on:
-                tm = torch.tensor([eh], device=dev, dtype=torch.float64)
-                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-                eh = float(tm)
-            ops.check_token_ids(wait=True)
-            h2d = {"value": round(B * world * n_h2d / eh, 2), "unit": "pairs/s", "ms_per_step": round(1e3 * eh / n_h2d, 2),
-                   "steps": n_h2d, "loss": round(float(loss_h), 4),
-                   "input": f"uint8 NHWC {stage}x{stage} staged images in pinned host memory -> DevicePrefetcher (depth 2, copy "
-                            f"stream) -> on-device RandomResizedCrop(scale 0.4-1, bicubic) + ColorJitter(0.32, 0.32, 0.32, 0.08; p=0.8) + Grayscale(p=0.2) -> {args.image_size} px"}
-            del pool, feed
-        except (RuntimeError, torch.OutOfMemoryError) as e:                      # the headline line must survive
-            h2d = {"value": None, "error": str(e)[:200]}
-
     if args.unpad_steps > 0 and not args.unpad_text:
         unpad = unpad_region()
 
@@ -772,7 +774,7 @@ def main():
             "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
             "peak_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2**30, 1),
             "alloc_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)),
-            "kernel_ms_per_step": round(sum(v["ms"] for k, v in prof.items() if "|" not in k) / args.steps, 2),
+            "kernel_ms_per_step": round(sum(v["ms"] for k, v in prof.items() if "|" not in k and "#" not in k) / args.steps, 2),
             "gather_wait_ms_per_step": round(gather_wait_ms, 3)}
     per_rank = [mine]
     if dist_on:
@@ -827,7 +829,7 @@ def main():
             "mfu_reference_flops": round(pairs_s / world * gf / 1e3 / mfu_peak, 4),
             "mfu_peak_tflops": mfu_peak, "executed_gflop_per_pair": round(gf - gf_pruned, 2),
             "alloc_conf": args.alloc_conf, "loss": round(last_loss, 4), "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
-            "peak_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2**30, 1),
+            "peak_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2**30, 1), "peak_reserved_gb_through_timed_region": round(reserved_timed / 2**30, 1),
             "alloc_retries": retries_timed,
             "alloc_retries_incl_extra_regions": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)),
             "keep_plan_backoffs": backoffs, "memory_pressure_backoffs": pressure_backoffs,
@@ -842,11 +844,17 @@ def main():
                          "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": round(nt.get("bytes", 0.0) / max(nt["launches"], 1)),
                          "launches": nt["launches"],
-                         "avg_launch_ms": round(nt["ms"] / max(nt["launches"], 1), 4)},
+                         "avg_launch_ms": round(nt["ms"] / max(nt["launches"], 1), 4),
+                         # the family by epilogue (epi0 plain / bias, 1 GELU, 1+pre8 GELU + e4m3 copy, 2 residual add, 3 GELU-backward,
+                         # 3,aux8 the same from e4m3 bytes, 3,aux8+act ... also writing the re-materialised GELU output - an HBM-bound
+                         # pass folded into that launch): TFLOP/s and ms per step
+                         "by_epilogue": {k[8:]: {"tflops": round(v["work"] / max(v["ms"], 1e-9) / 1e9, 1), "ms_per_step": round(v["ms"] / args.steps, 2),
+                                                  "launches_per_step": v["launches"] // args.steps}
+                                         for k, v in sorted(prof.items()) if k.startswith("gemm_nt#")} if dom == "gemm_nt" else None},
             "value_exact_tiers": exact,
             "h2d_inclusive": h2d,
             "unpadded_text": unpad,
-            "kernels": {k: kernel_entry(v, args.steps) for k, v in prof.items() if "|" not in k},
+            "kernels": {k: kernel_entry(v, args.steps) for k, v in prof.items() if "|" not in k and "#" not in k},
         }
         if args.shapes:
             for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):

@@ -371,7 +371,7 @@ extern "C" int clipa_gemm_nt(const void* A, const void* B, void* C, void* C2, co
   if (pre8) epi = CLIPA_EPI_ACT;
   if (aux8) epi = CLIPA_EPI_DACT;
   if ((epi == CLIPA_EPI_ADD || epi == CLIPA_EPI_DACT) && (!aux || ldaux % 8 != 0)) { clipa_set_error("gemm_nt: epilogue %d needs aux with ldaux%%8==0", epi); return CLIPA_ERR_ARG; }
-  if (C2 && epi != CLIPA_EPI_ACT) { clipa_set_error("gemm_nt: C2 (pre-activation copy) goes with CLIPA_EPI_ACT only"); return CLIPA_ERR_ARG; }
+  if (C2 && epi != CLIPA_EPI_ACT && !aux8) { clipa_set_error("gemm_nt: C2 goes with CLIPA_EPI_ACT (pre-activation copy) or CLIPA_EPI_DACT8 (activation output) only"); return CLIPA_ERR_ARG; }
   if (out_f32 && epi != CLIPA_EPI_NONE) { clipa_set_error("gemm_nt: f32 output supports epilogue NONE only"); return CLIPA_ERR_ARG; }
   if (256 * lda * 2 >= (1L << 30) || 256 * ldb * 2 >= (1L << 30) || 256 * ldc * 2 >= (1L << 30) || 256 * ldaux * 2 >= (1L << 30)) { clipa_set_error("gemm_nt: leading dimension too large"); return CLIPA_ERR_ARG; }
   int dev = 0;

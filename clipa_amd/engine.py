@@ -305,7 +305,10 @@ def _block_backward(x, dy, box, P, cfg):
     if hpre is None:     # "medium" block: LN2 + c_fc again (one GEMM instead of four + attention)
         h2 = ops.layernorm_fwd(x1, P["ln2_w"], P["ln2_b"], cfg["eps"])
         g, hpre = ops.gemm_nt(h2, P["w_fc"], P["b_fc"], epi=ops.EPI_ACT, act=act, want_pre=True)
-    elif g is None:      # "light" block: cheap HBM-bound re-materialisation instead of 4 GEMMs + attention
+    # "light8" block: the GELU-backward epilogue below reads the e4m3 bytes anyway and writes act(hpre) beside its own output
+    # (round 6: one more store per chunk instead of an HBM-bound pass over the same bytes; bit for bit what activation_fwd writes)
+    fuse_act = g is None and hpre is not None and hpre.dtype == torch.uint8
+    if g is None and hpre is not None and not fuse_act:      # "light" block: cheap HBM-bound re-materialisation instead of 4 GEMMs + attention
         g = ops.activation_fwd(hpre, act)
     # LayerNorm outputs that only the weight gradients still need (h2 of a block that kept or re-materialised its MLP
     # intermediates, h1 of a block that kept qkv) are written by the LayerNorm BACKWARD pass, which has every row and its
@@ -315,10 +318,16 @@ def _block_backward(x, dy, box, P, cfg):
     emit2, emit1 = h2 is None, h1 is None
     # y = x1 + c_proj(g).  The weight gradient goes first: g ([M, 4D], the largest transient of the block) is released before
     # the GELU-backward GEMM allocates its output of the same size
-    d_w_proj, d_b_proj = ops.gemm_tn(dy, g, P["dt_w_proj"], want_colsum=True)
-    del g
-    dh = ops.gemm_nt(dy, P["wt_proj"], epi=ops.EPI_DACT, act=act, aux=hpre)     # [M,4D]
-    del hpre
+    if fuse_act:         # (here g and dh coexist: dy + g + dh = 1.65 GB more than the block's later peak dh + dh2 + dx1 + h2 + dy)
+        dh, g = ops.gemm_nt(dy, P["wt_proj"], epi=ops.EPI_DACT, act=act, aux=hpre, want_act=True)
+        del hpre
+        d_w_proj, d_b_proj = ops.gemm_tn(dy, g, P["dt_w_proj"], want_colsum=True)
+        del g
+    else:
+        d_w_proj, d_b_proj = ops.gemm_tn(dy, g, P["dt_w_proj"], want_colsum=True)
+        del g
+        dh = ops.gemm_nt(dy, P["wt_proj"], epi=ops.EPI_DACT, act=act, aux=hpre)     # [M,4D]
+        del hpre
     dh2 = ops.gemm_nt(dh, P["wt_fc"])       # [M,D]
     if emit2:
         dx1, d_ln2_w, d_ln2_b, h2 = ops.layernorm_bwd(x1, P["ln2_w"], dh2, dres=dy, eps=cfg["eps"], beta=P["ln2_b"])

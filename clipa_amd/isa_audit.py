@@ -64,12 +64,12 @@ def epilogue_store_counts(path, txt):
     problems, kernel, open_k, count, count8, copies = [], None, None, 0, 0, 0
 
     def want(kname):
-        """-> (16-byte stores, 8-byte stores) per epilogue copy.  gemm_nta_kernel<EPI, PRE (0 / 1 bf16 copy / 2 e4m3 copy), AUX8,
-        SCHED>, gemm_f8a_kernel<EPI, PRE (0 / 1 bf16 copy / 2 e4m3 copy), AUX8, OUTQ (e4m3 output: 8-byte stores), FMT>."""
+        """-> (16-byte stores, 8-byte stores) per epilogue copy.  gemm_nta_kernel<EPI, PRE (0 / 1 bf16 copy / 2 e4m3 copy / 3 bf16 activation output of the
+        GELU-backward epilogue), AUX8, SCHED>, gemm_f8a_kernel<EPI, PRE (0 / 1 bf16 copy / 2 e4m3 copy), AUX8, OUTQ (e4m3 output: 8-byte stores), FMT>."""
         m = re.search(r"gemm_nta_kernelILi(\d+)ELi(\d+)E", kname)
         if m:
             pre = int(m.group(2))
-            return 32 * (2 if pre == 1 else 1), 32 if pre == 2 else 0
+            return 32 * (2 if pre in (1, 3) else 1), 32 if pre == 2 else 0
         m = re.search(r"gemm_f8a_kernelILi(\d+)ELi(\d+)ELb([01])ELi(\d+)E", kname)
         pre, outq = (int(m.group(2)), int(m.group(4))) if m else (0, 0)
         return 32 * ((pre == 1) + (outq == 0)), 32 * ((pre == 2) + (outq != 0))

@@ -66,6 +66,8 @@ class _Timed:
             b = torch.cuda.Event(enable_timing=True)
             b.record()
             _PROF.setdefault(self.name, []).append((self.a, b, self.work, self.nbytes))
+            if self.name == "gemm_nt" and self.tag is not None:       # the family split by epilogue ("gemm_nt#epi3,aux8+act")
+                _PROF.setdefault("gemm_nt#" + self.tag[self.tag.index("epi"):], []).append((self.a, b, self.work, self.nbytes))
             if _DETAIL and self.tag is not None:
                 _PROF.setdefault(f"{self.name}|{self.tag}", []).append((self.a, b, self.work, self.nbytes))
         return False
@@ -122,10 +124,17 @@ def e4m3_to_bf16(x8):
 
 
 def gemm_nt(a, b, bias=None, *, epi=EPI_NONE, act=ACT_GELU_ERF, aux=None, alpha=1.0, out_f32=False,
-            want_pre=False, out=None):
+            want_pre=False, out=None, want_act=False):
     """C[M,N] = epi(alpha * a[M,K] @ b[N,K]^T + bias). a, b bf16; bias f32 [N].
     want_pre: True -> also the bf16 pre-activation; "e4m3" -> it as saturating e4m3 bytes (uint8 [M,N], the "light8" keep tier:
-    fused into the epilogue on whole-tile shapes, GEMM + cast otherwise).  aux of EPI_DACT may be such a uint8 tensor."""
+    fused into the epilogue on whole-tile shapes, GEMM + cast otherwise).  aux of EPI_DACT may be such a uint8 tensor;
+    want_act (with it): -> (C, act(aux) as bf16 [M,N]) - what activation_fwd(aux, act) returns, written by the epilogue that
+    reads the bytes anyway on whole-tile shapes (by activation_fwd otherwise)."""
+    if want_act:
+        if not (epi == EPI_DACT and aux is not None and aux.dtype == u8 and not want_pre and not out_f32):
+            raise RuntimeError("gemm_nt: want_act goes with EPI_DACT on an e4m3 (uint8) second operand")
+        if not _whole_tiles(a.shape[0], b.shape[0], a.shape[1]) or (out is not None and out.stride(0) != b.shape[0]):
+            return gemm_nt(a, b, bias, epi=epi, act=act, aux=aux, alpha=alpha, out=out), activation_fwd(aux, act)
     if want_pre == "e4m3" and not (epi == EPI_ACT and not out_f32 and _whole_tiles(a.shape[0], b.shape[0], a.shape[1])):
         o, pre = gemm_nt(a, b, bias, epi=epi, act=act, aux=aux, alpha=alpha, want_pre=True, out=out)
         return o, cast_e4m3(pre)
@@ -148,7 +157,7 @@ def gemm_nt(a, b, bias=None, *, epi=EPI_NONE, act=ACT_GELU_ERF, aux=None, alpha=
         out = torch.empty((M, N), device=a.device, dtype=f32 if out_f32 else bf16)
     ldc = out.stride(0) if M > 1 else N
     pre8 = want_pre == "e4m3"
-    pre = torch.empty((M, N), device=a.device, dtype=u8 if pre8 else bf16) if want_pre else None
+    pre = torch.empty((M, N), device=a.device, dtype=u8 if pre8 else bf16) if (want_pre or want_act) else None
     if pre8 and ldc != N:
         raise RuntimeError("gemm_nt: want_pre='e4m3' needs a dense output (the copy shares its row stride)")
     ldaux, aux_sz = 0, 2
@@ -164,11 +173,13 @@ def gemm_nt(a, b, bias=None, *, epi=EPI_NONE, act=ACT_GELU_ERF, aux=None, alpha=
     osz = 4 if out_f32 else 2
     nbytes = 2.0 * (M * K + N * K) + osz * M * N + (float(aux_sz) * M * N if aux is not None else 0) + \
         ((1.0 if pre8 else 2.0) * M * N if want_pre else 0)
-    tag_epi = {EPI_ACT_PRE8: "1+pre8", EPI_DACT8: "3,aux8"}.get(epi, f"{epi}{'+pre' if want_pre else ''}")
+    if want_act:
+        nbytes += 2.0 * M * N
+    tag_epi = {EPI_ACT_PRE8: "1+pre8", EPI_DACT8: "3,aux8+act" if want_act else "3,aux8"}.get(epi, f"{epi}{'+pre' if want_pre else ''}")
     with _Timed("gemm_nt", 2.0 * M * N * K, nbytes, f"{M},{N},{K},epi{tag_epi}{',f32' if out_f32 else ''}"):
         lib.call("clipa_gemm_nt", _p(a), _p(b), _p(out), _p(pre), _p(bias), _p(aux), M, N, K, lda, ldb, ldc, ldaux,
                  float(alpha), epi, act, 1 if out_f32 else 0, _stream())
-    return (out, pre) if want_pre else out
+    return (out, pre) if (want_pre or want_act) else out
 
 
 FMT_E4M3, FMT_E5M2 = 0, 1
@@ -312,7 +323,9 @@ def gemm_nt_f8(a8, sa, b8, sb, bias=None, *, epi=EPI_NONE, act=ACT_GELU_ERF, aux
         epi = EPI_ACT_PRE8
     nbytes = 1.0 * (M * K + N * K) + 2.0 * M * N + (float(aux_sz) * M * N if aux is not None else 0) + \
         ((1.0 if pre8 else 2.0) * M * N if want_pre else 0)
-    tag_epi = {EPI_ACT_PRE8: "1+pre8", EPI_DACT8: "3,aux8"}.get(epi, f"{epi}{'+pre' if want_pre else ''}")
+    if want_act:
+        nbytes += 2.0 * M * N
+    tag_epi = {EPI_ACT_PRE8: "1+pre8", EPI_DACT8: "3,aux8+act" if want_act else "3,aux8"}.get(epi, f"{epi}{'+pre' if want_pre else ''}")
     with _Timed("gemm_nt_f8", 2.0 * M * N * K, nbytes, f"{M},{N},{K},epi{tag_epi}"):
         lib.call("clipa_gemm_nt_f8", _p(a8), _p(b8), _p(sa), _p(sb), _p(out), _p(pre), _p(bias), _p(aux), M, N, K, lda, ldb,
                  N, ldaux, float(alpha), epi, act, int(fmt_a), int(fmt_b), _stream())

@@ -27,7 +27,8 @@ extern "C" {
  * the HBM of the bf16 copy.  Whole-tile shapes only (M, N multiples of 256, K multiple of 128, K >= 256): other shapes return
  * CLIPA_ERR_ARG and the caller composes CLIPA_EPI_ACT + clipa_cast_bf16_to_e4m3 / clipa_cast_e4m3_to_bf16 + CLIPA_EPI_DACT. */
 #define CLIPA_EPI_ACT_PRE8 4 /* C = act(v), C2 = e4m3(v): uint8 [M, ldc]                      */
-#define CLIPA_EPI_DACT8 5    /* C = v * act'(aux), aux = e4m3 bytes, uint8 [M, ldaux]          */
+#define CLIPA_EPI_DACT8 5    /* C = v * act'(aux), aux = e4m3 bytes, uint8 [M, ldaux]; optional C2 = act(aux), bf16 [M, ldc]:
+                              * what clipa_activation_fwd_e4m3 writes for the same bytes (the c_proj weight gradient's operand) */
 /* activations: nn.GELU(approximate='none'|'tanh') (model.py:128-129), QuickGELU (transformer.py:37-40) */
 #define CLIPA_ACT_GELU_ERF 0
 #define CLIPA_ACT_GELU_TANH 1

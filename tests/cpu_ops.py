@@ -34,7 +34,9 @@ def _from_e4m3(x8):
     return x8.view(torch.float8_e4m3fn).float()
 
 
-def gemm_nt(a, b, bias=None, *, epi=EPI_NONE, act=0, aux=None, alpha=1.0, out_f32=False, want_pre=False, out=None):
+def gemm_nt(a, b, bias=None, *, epi=EPI_NONE, act=0, aux=None, alpha=1.0, out_f32=False, want_pre=False, out=None, want_act=False):
+    if want_act:
+        return gemm_nt(a, b, bias, epi=epi, act=act, aux=aux, alpha=alpha), activation_fwd(aux, act)
     v = (a.float() @ b.float().T) * alpha
     if bias is not None:
         v = v + bias.float()

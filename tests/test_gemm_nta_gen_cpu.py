@@ -65,7 +65,7 @@ def test_isa_audit(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     a = subprocess.run([sys.executable, os.path.join(ROOT, "clipa_amd", "isa_audit.py"), str(asm)], capture_output=True, text=True)
     assert a.returncode == 0, a.stdout[-3000:]
-    assert len(re.findall(r"\.name:\s+\S*gemm_nta_kernel", asm.read_text())) == 21      # 7 epilogue flavours (5 + the two e4m3 ones) x 3 schedules
+    assert len(re.findall(r"\.name:\s+\S*gemm_nta_kernel", asm.read_text())) == 24      # 8 epilogue flavours (5 + the three e4m3 ones) x 3 schedules
 
 
 @pytest.mark.parametrize("sched", [0, 1])

@@ -177,6 +177,21 @@ def test_gemm_nt_e4m3_pre_activation_epilogues(M, N, K):
     d16 = o.gemm_nt(dy, w2, epi=o.EPI_DACT, act=0, aux=hb)
     assert torch.equal(d8, d16)
     assert torch.equal(o.activation_fwd(h8, 0), o.activation_fwd(hb, 0))
+    # ... and the same launch writing act(h8) beside its output (round 6: gemm_nta<DACT, PRE = 3, AUX8>; the c_proj weight
+    # gradient's operand without an activation_fwd pass): both outputs bit for bit those of the two separate launches, every
+    # activation, every finite e4m3 code present in the operand
+    codes = torch.arange(256, dtype=torch.uint8)
+    codes = codes[(codes & 0x7f) != 0x7f]
+    h8[0, :codes.numel()] = codes.to(DEV)
+    from clipa_amd import lib as _lib
+    for act in (0, 1, 2):
+        _lib.gemm_counts(reset=True)
+        dh, g = o.gemm_nt(dy, w2, epi=o.EPI_DACT, act=act, aux=h8, want_act=True)
+        assert _lib.gemm_counts()[15] == (1 if whole else 0)
+        assert torch.equal(dh, o.gemm_nt(dy, w2, epi=o.EPI_DACT, act=act, aux=h8)), act
+        assert torch.equal(g, o.activation_fwd(h8, act)), act
+        dh2, g2 = o.gemm_nt(dy, w2, epi=o.EPI_DACT, act=act, aux=h8, want_act=True)
+        assert torch.equal(dh, dh2) and torch.equal(g, g2)
 
 
 def test_gemm_nt_ragged_shapes_every_epilogue():

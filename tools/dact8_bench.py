@@ -51,10 +51,13 @@ for M, N, K in shapes:
         wq, ws = ops.quantize_rows(w)
         cases = {"plain": lambda: ops.gemm_nt_f8(dq, ds, wq, ws), "dact8": lambda: ops.gemm_nt_f8(dq, ds, wq, ws, epi=ops.EPI_DACT, aux=h8)}
     else:
-        cases = {"plain": lambda: ops.gemm_nt(dy, w), "dact8": lambda: ops.gemm_nt(dy, w, epi=ops.EPI_DACT, aux=h8)}
+        cases = {"plain": lambda: ops.gemm_nt(dy, w), "dact8": lambda: ops.gemm_nt(dy, w, epi=ops.EPI_DACT, aux=h8),
+                 "dact8_act": lambda: ops.gemm_nt(dy, w, epi=ops.EPI_DACT, aux=h8, want_act=True)}
     for name, fn in cases.items():
         ms = timed(fn)
         rec[name + "_ms"], rec[name + "_tflops"] = round(ms, 3), round(2.0 * M * N * K / ms / 1e9, 1)
+    if not args.f8:
+        rec["activation_fwd_e4m3_ms"] = round(timed(lambda: ops.activation_fwd(h8, 0)), 3)
     out = cases["dact8"]()
     rec["checksum"] = float(out.float().abs().sum())
     print(json.dumps(rec), flush=True)
