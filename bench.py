@@ -220,6 +220,34 @@ def cpu_baseline(cfg, S, ctx, sample_pairs, threads):
                       f"oracle/clip_oracle.py on torch CPU ops"}
 
 
+def fp8_child_line(args):
+    """The same workload in fp8 (forward, input-gradient and weight-gradient products of the block linears on
+    v_mfma_f32_16x16x128_f8f6f4), measured by a child process while this one has not allocated anything on the GPU yet.
+    -> the summary that goes into the bench line as `fp8_same_workload` (errors are reported there, never raised)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--precision", "fp8", "--model", args.model,
+           "--image-size", str(args.image_size), "--ctx", str(args.ctx), "--batch", str(args.batch), "--accum-freq", str(args.accum_freq),
+           "--steps", str(args.fp8_line_steps), "--warmup", "1", "--no-cpu-baseline", "--h2d-steps", "0", "--plain-steps", "0",
+           "--exact-steps", "0", "--unpad-steps", "0", "--fp8-line-steps", "0"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.fp8_line_timeout, env=env)
+        rows = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not rows:
+            return {"value": None, "error": (r.stderr or r.stdout)[-300:]}
+        j = json.loads(rows[-1])
+        ro = j.get("roofline") or {}
+        return {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"], "dtype": j["dtype"],
+                "loss": j.get("loss"), "workload": j["config"]["workload"], "model_flops_util_of_fp8_peak": j.get("model_flops_util"),
+                "roofline": {k: ro.get(k) for k in ("kernel", "achieved", "peak", "unit", "frac")},
+                "note": "child process `bench.py --precision fp8` on the same model / batch before this process allocated on the GPU; "
+                        "parity of the fp8 step: tests/test_fp8_gpu.py"}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "error": f"timed out after {args.fp8_line_timeout}s"}
+    except Exception as e:      # the headline line must survive
+        return {"value": None, "error": repr(e)[:300]}
+
+
 def self_launch_argv(n_gpus, script_args, port=None):
     """`python bench.py --gpus N` (N > 1) outside a launcher: the argv this process re-executes itself with - one rank per GPU
     under torch.distributed.run on this node, rendezvous on 127.0.0.1 (the reference's `torchrun --nproc_per_node 8`,
@@ -293,6 +321,11 @@ def main():
                          "reported as `uninstrumented_ms_per_step` next to `ms_per_step` (0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=8, help="pairs per CPU-baseline step")
     ap.add_argument("--cpu-timeout", type=int, default=240)
+    ap.add_argument("--fp8-line-steps", type=int, default=3,
+                    help="one GPU, bf16 run: BEFORE this process touches the GPU, the same workload is measured in fp8 (BASELINE configs[3]'s "
+                         "precision; create_model(precision='fp8')) by a child `bench.py --precision fp8` with this many timed steps and "
+                         "reported as `fp8_same_workload`, never part of `value` (0 = skip)")
+    ap.add_argument("--fp8-line-timeout", type=int, default=300)
     args = ap.parse_args()
 
     if (args.gpus > 1 or os.environ.get("CLIPA_BENCH_FORCE_DIST") == "1") and "WORLD_SIZE" not in os.environ:
@@ -312,6 +345,9 @@ def main():
     if not torch.cuda.is_available():
         print(f"bench.py (rank {rank} of {world}): no GPU visible - the MI355X engine has no CPU fallback", file=sys.stderr)
         sys.exit(2)
+    fp8_line = None
+    if world == 1 and os.environ.get("CLIPA_BENCH_FORCE_DIST") != "1" and args.precision != "fp8" and args.fp8_line_steps > 0:
+        fp8_line = fp8_child_line(args)
     if args.alloc_conf:
         torch.cuda.memory._set_allocator_settings(args.alloc_conf)
     torch.cuda.set_device(local_rank)
@@ -851,6 +887,7 @@ def main():
                          "by_epilogue": {k[8:]: {"tflops": round(v["work"] / max(v["ms"], 1e-9) / 1e9, 1), "ms_per_step": round(v["ms"] / args.steps, 2),
                                                   "launches_per_step": v["launches"] // args.steps}
                                          for k, v in sorted(prof.items()) if k.startswith("gemm_nt#")} if dom == "gemm_nt" else None},
+            "fp8_same_workload": None if fp8_line is None else {**fp8_line, "over_value": (round(fp8_line["value"] / pairs_s, 3) if fp8_line.get("value") else None)},
             "value_exact_tiers": exact,
             "h2d_inclusive": h2d,
             "unpadded_text": unpad,

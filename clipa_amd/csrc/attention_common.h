@@ -43,6 +43,9 @@ struct WGHeads {
 // CU; four waves there leave every SIMD a single wave and nothing to overlap its MFMA -> softmax -> MFMA chain with, so those
 // instantiations run eight waves (two per SIMD, one 32-row tile each for all but one wave).
 template <int NKT, int DH>
+// (Round 6, "one tile per wave": 7 or 8 waves for the 7 tiles of 197 tokens need 154-165 registers each, which leaves ONE
+// workgroup per CU - forward 1.63 -> 2.03 ms, backward 4.76 -> 5.61 ms; 9 waves for the 9 tiles of 257 tokens at head dim 80 cap a
+// wave at 168 registers: 53-57 spills.  profiles/r06_attention_waves_per_workgroup_ab.jsonl)
 __host__ __device__ constexpr int attn_waves() { return (DH == 80 && NKT >= 5) ? 8 : 4; }   // (wider heads spill at 256 registers per wave)
 
 // chunk permutation of an LDS row: conflict-free for both the direct ds_read_b128 operand reads and the

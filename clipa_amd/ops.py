@@ -323,9 +323,7 @@ def gemm_nt_f8(a8, sa, b8, sb, bias=None, *, epi=EPI_NONE, act=ACT_GELU_ERF, aux
         epi = EPI_ACT_PRE8
     nbytes = 1.0 * (M * K + N * K) + 2.0 * M * N + (float(aux_sz) * M * N if aux is not None else 0) + \
         ((1.0 if pre8 else 2.0) * M * N if want_pre else 0)
-    if want_act:
-        nbytes += 2.0 * M * N
-    tag_epi = {EPI_ACT_PRE8: "1+pre8", EPI_DACT8: "3,aux8+act" if want_act else "3,aux8"}.get(epi, f"{epi}{'+pre' if want_pre else ''}")
+    tag_epi = {EPI_ACT_PRE8: "1+pre8", EPI_DACT8: "3,aux8"}.get(epi, f"{epi}{'+pre' if want_pre else ''}")
     with _Timed("gemm_nt_f8", 2.0 * M * N * K, nbytes, f"{M},{N},{K},epi{tag_epi}"):
         lib.call("clipa_gemm_nt_f8", _p(a8), _p(b8), _p(sa), _p(sb), _p(out), _p(pre), _p(bias), _p(aux), M, N, K, lda, ldb,
                  N, ldaux, float(alpha), epi, act, int(fmt_a), int(fmt_b), _stream())

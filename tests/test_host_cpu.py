@@ -417,3 +417,33 @@ def test_bench_self_launch_argv_and_no_gpu_exit():
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"],
                         capture_output=True, text=True, timeout=300, env=env)
     assert r1.returncode == 2 and "re-executing" not in r1.stderr and "rank 0 of 1): no GPU visible" in r1.stderr
+
+
+def test_bench_fp8_child_line_survives_a_failing_child():
+    """bench.py's `fp8_same_workload` (the headline workload measured in fp8 by a child process before the parent touches the
+    GPU; BASELINE configs[3]'s precision, training/params.py:195-200 stops at bf16): the child gets the parent's workload and
+    none of its extra regions, cannot recurse, and a child that fails (here: no GPU) turns into an error entry, not an exception."""
+    import argparse
+    import bench
+    if torch.cuda.is_available():
+        return
+    args = argparse.Namespace(model="ViT-S-16", image_size=112, ctx=32, batch=64, accum_freq=1, fp8_line_steps=2, fp8_line_timeout=300)
+    seen = {}
+    import subprocess
+    real = subprocess.run
+
+    def spy(cmd, **kw):
+        seen["cmd"] = cmd
+        return real(cmd, **kw)
+    subprocess.run = spy
+    try:
+        line = bench.fp8_child_line(args)
+    finally:
+        subprocess.run = real
+    cmd = seen["cmd"]
+    assert cmd[1] == os.path.join(ROOT, "bench.py")
+    for flag, val in (("--precision", "fp8"), ("--model", "ViT-S-16"), ("--batch", "64"), ("--image-size", "112"), ("--ctx", "32"),
+                      ("--steps", "2"), ("--fp8-line-steps", "0"), ("--h2d-steps", "0"), ("--exact-steps", "0"), ("--unpad-steps", "0")):
+        assert cmd[cmd.index(flag) + 1] == val, flag
+    assert "--no-cpu-baseline" in cmd
+    assert line["value"] is None and "no GPU visible" in line["error"]

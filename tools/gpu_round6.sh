@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 R="$PWD"
 O="$R/gpurun_out/r06"
 STAGES="${*:-h14}"
-H14="--model ViT-H-14 --batch 2048 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 --exact-steps 0 --unpad-steps 0"
+H14="--model ViT-H-14 --batch 2048 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 --exact-steps 0 --unpad-steps 0 --fp8-line-steps 0"
 for s in $STAGES; do
   case $s in
     h14)
@@ -19,7 +19,7 @@ for s in $STAGES; do
       done ;;
     cfg4)
       # BASELINE configs[3] at its own per-GPU batch (65536 / 8 = 8192) as four micro-batches with the reference's feature cache
-      timeout 900 python bench.py --model ViT-H-14 --batch 8192 --accum-freq 4 --precision fp8 --steps 2 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 --exact-steps 0 --unpad-steps 0 > $O/bench_h14_B8192_accum4_fp8.json 2> $O/bench_h14_B8192_accum4_fp8.err
+      timeout 900 python bench.py --model ViT-H-14 --batch 8192 --accum-freq 4 --precision fp8 --steps 2 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 --exact-steps 0 --unpad-steps 0 --fp8-line-steps 0 > $O/bench_h14_B8192_accum4_fp8.json 2> $O/bench_h14_B8192_accum4_fp8.err
       cut -c1-330 $O/bench_h14_B8192_accum4_fp8.json ;;
     stats8)
       # rocprofv3 kernel trace of the fp8 step (summary only travels back)
@@ -29,7 +29,7 @@ for s in $STAGES; do
       [ -n "$db" ] && python tools/rocpd_stats.py "$db" $O/kernel_stats_h14_fp8.csv | head -16
       rm -rf $O/prof8 ;;
     stats)
-      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$O/prof" -o r06 -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 --exact-steps 0 --unpad-steps 0 > "$O/bench_B4096_under_rocprof.json" 2> "$O/bench_B4096_under_rocprof.err")
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$O/prof" -o r06 -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --h2d-steps 0 --plain-steps 0 --exact-steps 0 --unpad-steps 0 --fp8-line-steps 0 > "$O/bench_B4096_under_rocprof.json" 2> "$O/bench_B4096_under_rocprof.err")
       cut -c1-300 $O/bench_B4096_under_rocprof.json
       db=$(find $O/prof -name '*.db' | head -1)
       [ -n "$db" ] && python tools/rocpd_stats.py "$db" $O/kernel_stats_B4096.csv | head -16
@@ -37,7 +37,7 @@ for s in $STAGES; do
     pmc8|pmc)
       # one bench step per counter set, each in its own rocprofv3 pass (MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE never share a
       # pass; no tracing domains next to --pmc)
-      if [ $s = pmc8 ]; then ARGS="$H14 --precision fp8"; D=$O/pmc8; else ARGS="--no-cpu-baseline --h2d-steps 0 --plain-steps 0 --exact-steps 0 --unpad-steps 0"; D=$O/pmc; fi
+      if [ $s = pmc8 ]; then ARGS="$H14 --precision fp8"; D=$O/pmc8; else ARGS="--no-cpu-baseline --h2d-steps 0 --plain-steps 0 --exact-steps 0 --unpad-steps 0 --fp8-line-steps 0"; D=$O/pmc; fi
       mkdir -p $D
       declare -A SETS=( [FETCH_SIZE]="FETCH_SIZE" [WRITE_SIZE]="WRITE_SIZE"
                         [MFMA]="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"
