@@ -8,6 +8,7 @@
 // dgamma / dbeta partials, gives every block 128 ADJACENT rows (5.4 TB/s including the partial reduction, 4.4 persistent)
 // - for rows of at most 1024 elements; wider rows stay on the persistent grid (ln_bwd_chunk).
 #include "common.h"
+#include "quant_common.h"
 #include "clipa_hip.h"
 
 namespace {
@@ -112,12 +113,21 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
 // weight-gradient GEMM of the layer that followed the LayerNorm: a block that recomputes that operand in backward gets it from
 // the pass that has the row and its statistics in registers anyway (one more 2 D-byte store per row) instead of from a second
 // ln_fwd launch over the same rows (a 2 D-byte read and a 2 D-byte write per row).
-template <int NCH, bool XF32, bool YF32, bool EMIT = false>
+// QFMT >= 0 (round 6, fp8 engine; bf16 rows only): dx is also the incoming gradient of the linear layer in front of this
+// LayerNorm's block position, whose two fp8 products want it row-quantised with its column sums (= that layer's bias gradient):
+// this pass has the finished row in registers, so it writes the e4m3 / e5m2 bytes, the row scale and per-block column-sum
+// partials itself (q, dq bit for bit what clipa_quantize_rows makes of the bf16 dx; one more byte per element instead of a
+// pass that reads 2 and writes 1).  part then holds [3][gridDim.x][D]: dgamma, dbeta, column sums of dx.
+template <int NCH, bool XF32, bool YF32, bool EMIT = false, int QFMT = -1>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
                                                      const void* __restrict__ dy, const void* __restrict__ dres,
                                                      void* __restrict__ dx, float* __restrict__ part,
                                                      long rows, int D, float eps, int C,
-                                                     const float* __restrict__ beta = nullptr, void* __restrict__ yout = nullptr) {
+                                                     const float* __restrict__ beta = nullptr, void* __restrict__ yout = nullptr,
+                                                     char* __restrict__ q8 = nullptr, float* __restrict__ q8scale = nullptr,
+                                                     float* __restrict__ q8norm = nullptr) {
+  constexpr bool QOUT = QFMT >= 0;
+  static_assert(!QOUT || (!XF32 && !YF32), "the quantised output exists for bf16 rows");
   // Every multiply-add of the statistics and of the outputs is WRITTEN as __builtin_fmaf, here and in ln_fwd_kernel (and in the
   // LayerNorm + quantise kernels of quant.hip): which products hipcc contracts under -ffp-contract=fast depends on use counts that
   // differ between instantiations (and `#pragma clang fp contract(off)` is ignored under that flag - ADVICE r5), while the EMIT,
@@ -132,12 +142,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
   const long row_first = C ? (long)blockIdx.x * C + wv : (long)blockIdx.x * 4 + wv;
   const long row_step = C ? 4 : (long)gridDim.x * 4;
   const int nchunks = D >> 3;
-  float g[NCH][8], dg[NCH][8], db[NCH][8];
+  float g[NCH][8], dg[NCH][8], db[NCH][8], cs[QOUT ? NCH : 1][8];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int ch = lane + c * 64;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { dg[c][i] = 0.f; db[c][i] = 0.f; g[c][i] = 0.f; }
+    for (int i = 0; i < 8; ++i) { dg[c][i] = 0.f; db[c][i] = 0.f; g[c][i] = 0.f; if (QOUT) cs[c][i] = 0.f; }
     if (ch < nchunks) ld8<true, false>(gamma, (size_t)ch * 8, g[c]);
   }
   // (EMIT: beta is re-read per row from L1 / L2 - 4 KB shared by every wave - rather than held in NCH * 8 more registers)
@@ -217,6 +227,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
       }
     }
     const float m1 = wave_sum(s1) * invD, m2 = wave_sum(s2) * invD;
+    float amax = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + c * 64;
@@ -231,7 +242,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
 #pragma unroll
           for (int i = 0; i < 8; ++i) o[i] += rr[i];
         }
-        st8<XF32>(dx, (size_t)r * D + (size_t)ch * 8, o);
+        if constexpr (QOUT) {      // the stored bf16 values are what gets quantised: d (dxhat, dead from here) keeps them for the second sweep
+          const u32x4 pk = pack8(o);
+          __builtin_nontemporal_store(pk, (u32x4*)((unsigned short*)dx + (size_t)r * D + (size_t)ch * 8));
+          unpack8(pk, d[c]);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(d[c][i]));
+        } else {
+          st8<XF32>(dx, (size_t)r * D + (size_t)ch * 8, o);
+        }
         if constexpr (EMIT) {      // v holds xhat = (x - mean) * rstd: y = xhat * gamma + beta, ln_fwd_kernel's expression (tested)
           float bt[8];
           ld8<true, false>(beta, (size_t)ch * 8, bt);
@@ -239,6 +258,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
           for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf(v[c][i], g[c][i], bt[i]);
           st8<YF32>(yout, (size_t)r * D + (size_t)ch * 8, o);
         }
+      }
+    }
+    if constexpr (QOUT) {
+      float qs, qd, ssq = 0.f;
+      row_scales<QFMT>(wave_max(amax), qs, qd);
+      if (lane == 0) q8scale[r] = qd;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunks) {
+          __builtin_nontemporal_store(cvt8<QFMT>(d[c], qs), (u32x2*)(q8 + (size_t)r * D + (size_t)ch * 8));
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { cs[c][i] += d[c][i]; ssq = __builtin_fmaf(d[c][i], d[c][i], ssq); }
+        }
+      }
+      if (q8norm) {
+        ssq = wave_sum(ssq);
+        if (lane == 0) q8norm[r] = sqrtf(ssq);
       }
     }
   }
@@ -263,37 +300,58 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
     for (int w = 0; w < 4; ++w) a += sd[(w * 2 + which) * D + col];
     part[((size_t)which * gridDim.x + blockIdx.x) * D + col] = a;
   }
+  if constexpr (QOUT) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunks) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sd[wv * D + ch * 8 + i] = cs[c][i];
+      }
+    }
+    __syncthreads();
+    for (int col = threadIdx.x; col < D; col += 256)
+      part[((size_t)2 * gridDim.x + blockIdx.x) * D + col] = (sd[col] + sd[D + col]) + (sd[2 * D + col] + sd[3 * D + col]);
+  }
 }
 
-// out_g[y][col] = sum over the partial rows b of slice y of part[0][b][col], out_b likewise from part[1]:
-// 64 columns per block, 4 waves striding the slice (4 independent loads in flight per lane).  Many partial rows are reduced in
-// two passes (gridDim.y slices -> [2][slices][D], then one slice over those) so that the first pass fills the chip.
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ out_g,
-                                                            float* __restrict__ out_b, int nblk, int D, int per) {
-  __shared__ float red[2][4][64];
+// out_a[y][col] = sum over the partial rows b of slice y of part[a][b][col] for the NA arrays of a launch (dgamma, dbeta and -
+// the quantising backward - the column sums of dx): 64 columns per block, 4 waves striding the slice (independent loads in
+// flight per lane).  Many partial rows are reduced in two passes (gridDim.y slices -> [NA][slices][D], then one slice over
+// those) so that the first pass fills the chip.  Fixed order: bit-reproducible.
+template <int NA>
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ out0,
+                                                            float* __restrict__ out1, float* __restrict__ out2, int nblk, int D, int per) {
+  __shared__ float red[NA][4][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + lane;
   const int lo = blockIdx.y * per, hi = lo + per < nblk ? lo + per : nblk;
-  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+  float a0[NA], a1[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) { a0[a] = 0.f; a1[a] = 0.f; }
   if (col < D) {
     int s = lo + grp;
     for (; s + 4 < hi; s += 8) {
-      a0 += part[(size_t)s * D + col];
-      a1 += part[(size_t)(s + 4) * D + col];
-      b0 += part[((size_t)nblk + s) * D + col];
-      b1 += part[((size_t)nblk + s + 4) * D + col];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        a0[a] += part[((size_t)a * nblk + s) * D + col];
+        a1[a] += part[((size_t)a * nblk + s + 4) * D + col];
+      }
     }
     for (; s < hi; s += 4) {
-      a0 += part[(size_t)s * D + col];
-      b0 += part[((size_t)nblk + s) * D + col];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) a0[a] += part[((size_t)a * nblk + s) * D + col];
     }
   }
-  red[0][grp][lane] = a0 + a1;
-  red[1][grp][lane] = b0 + b1;
+#pragma unroll
+  for (int a = 0; a < NA; ++a) red[a][grp][lane] = a0[a] + a1[a];
   __syncthreads();
   if (grp == 0 && col < D) {
-    out_g[(size_t)blockIdx.y * D + col] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
-    out_b[(size_t)blockIdx.y * D + col] = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+    float* outs[3] = {out0, out1, out2};
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+      outs[a][(size_t)blockIdx.y * D + col] = red[a][0][lane] + red[a][1][lane] + red[a][2][lane] + red[a][3][lane];
   }
 }
 
@@ -335,8 +393,18 @@ void launch_fwd(const void* x, const float* g, const float* b, void* y, long row
 template <int NCH>
 void launch_bwd(const void* x, const float* g, const void* dy, const void* dres, void* dx, float* part,
                 long rows, int D, float eps, int xf32, int yf32, int grid, int C, hipStream_t st,
-                const float* beta = nullptr, void* yout = nullptr) {
+                const float* beta = nullptr, void* yout = nullptr, int qfmt = -1, char* q8 = nullptr, float* q8scale = nullptr,
+                float* q8norm = nullptr) {
   const size_t lds = (size_t)8 * D * sizeof(float);
+  if (qfmt >= 0) {     // bf16 rows (checked by the caller)
+#define LN_BWD_Q(E, F) hipLaunchKernelGGL((ln_bwd_kernel<NCH, false, false, E, F>), dim3(grid), dim3(256), lds, st, x, g, dy, dres, dx, part, rows, D, eps, C, beta, yout, q8, q8scale, q8norm)
+    if (yout && qfmt == 0) LN_BWD_Q(true, 0);
+    else if (yout) LN_BWD_Q(true, 1);
+    else if (qfmt == 0) LN_BWD_Q(false, 0);
+    else LN_BWD_Q(false, 1);
+#undef LN_BWD_Q
+    return;
+  }
   if (yout) {     // the emitting form: the engine's bf16 token matrices and the f32 rows of the heads
     if (xf32 && yf32) hipLaunchKernelGGL((ln_bwd_kernel<NCH, true, true, true>), dim3(grid), dim3(256), lds, st, x, g, dy, dres, dx, part, rows, D, eps, C, beta, yout);
     else if (xf32) hipLaunchKernelGGL((ln_bwd_kernel<NCH, true, false, true>), dim3(grid), dim3(256), lds, st, x, g, dy, dres, dx, part, rows, D, eps, C, beta, yout);
@@ -367,11 +435,15 @@ extern "C" int clipa_layernorm_fwd(const void* x, const float* gamma, const floa
 extern "C" int64_t clipa_layernorm_bwd_workspace(int64_t rows, int64_t D) {
   return (int64_t)2 * (ln_bwd_grid(rows, D) + LN_BWD_SLICES) * D * sizeof(float);   // [2][blocks][D] + [2][slices][D]
 }
+extern "C" int64_t clipa_layernorm_bwd_q8_workspace(int64_t rows, int64_t D) {
+  return (int64_t)3 * (ln_bwd_grid(rows, D) + LN_BWD_SLICES) * D * sizeof(float);   // [3][blocks][D] + [3][slices][D]
+}
 
 namespace {
 int ln_bwd_impl(const void* x, const float* gamma, const float* beta, const void* dy, const void* dres, void* dx, void* y,
                 float* dgamma, float* dbeta, int64_t rows, int64_t D, float eps, int x_f32, int y_f32, void* workspace,
-                int64_t workspace_bytes, void* stream);
+                int64_t workspace_bytes, void* stream, int qfmt = -1, void* q8 = nullptr, float* q8scale = nullptr,
+                float* colsum = nullptr, float* q8norm = nullptr);
 }
 
 extern "C" int clipa_layernorm_bwd(const void* x, const float* gamma, const void* dy, const void* dres,
@@ -392,28 +464,43 @@ extern "C" int clipa_layernorm_bwd_y(const void* x, const float* gamma, const fl
 namespace {
 int ln_bwd_impl(const void* x, const float* gamma, const float* beta, const void* dy, const void* dres, void* dx, void* y,
                 float* dgamma, float* dbeta, int64_t rows, int64_t D, float eps, int x_f32, int y_f32, void* workspace,
-                int64_t workspace_bytes, void* stream) {
+                int64_t workspace_bytes, void* stream, int qfmt, void* q8, float* q8scale, float* colsum, float* q8norm) {
   if (D % 8 != 0 || D <= 0 || D > 2048) { clipa_set_error("layernorm: D=%ld must be a multiple of 8 in (0, 2048]", (long)D); return CLIPA_ERR_ARG; }
   if (rows <= 0) return CLIPA_OK;
-  if (!workspace || workspace_bytes < clipa_layernorm_bwd_workspace(rows, D)) { clipa_set_error("layernorm_bwd: workspace too small"); return CLIPA_ERR_ARG; }
+  const bool Q = qfmt >= 0;
+  if (!workspace || workspace_bytes < (Q ? clipa_layernorm_bwd_q8_workspace(rows, D) : clipa_layernorm_bwd_workspace(rows, D))) { clipa_set_error("layernorm_bwd: workspace too small"); return CLIPA_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
   const int grid = (int)ln_bwd_grid(rows, D), C = ln_bwd_chunk(rows, D);
   float* part = (float*)workspace;
-  if (D <= 512) launch_bwd<1>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, C, st, beta, y);
-  else if (D <= 1024) launch_bwd<2>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, C, st, beta, y);
-  else if (D <= 1536) launch_bwd<3>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, C, st, beta, y);
-  else launch_bwd<4>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, C, st, beta, y);
+  if (D <= 512) launch_bwd<1>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, C, st, beta, y, qfmt, (char*)q8, q8scale, q8norm);
+  else if (D <= 1024) launch_bwd<2>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, C, st, beta, y, qfmt, (char*)q8, q8scale, q8norm);
+  else if (D <= 1536) launch_bwd<3>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, C, st, beta, y, qfmt, (char*)q8, q8scale, q8norm);
+  else launch_bwd<4>(x, gamma, dy, dres, dx, part, rows, (int)D, eps, x_f32, y_f32, grid, C, st, beta, y, qfmt, (char*)q8, q8scale, q8norm);
   if (int rc = clipa_check_launch("layernorm_bwd")) return rc;
   const unsigned cols = (unsigned)((D + 63) / 64);
+  const int NA = Q ? 3 : 2;
+#define LN_REDUCE(GRID, ...) do { if (Q) hipLaunchKernelGGL(ln_bwd_reduce_kernel<3>, GRID, dim3(256), 0, st, __VA_ARGS__); \
+                                  else hipLaunchKernelGGL(ln_bwd_reduce_kernel<2>, GRID, dim3(256), 0, st, __VA_ARGS__); } while (0)
   if (grid <= 8 * LN_BWD_SLICES) {
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cols), dim3(256), 0, st, part, dgamma, dbeta, grid, (int)D, grid);
+    LN_REDUCE(dim3(cols), part, dgamma, dbeta, colsum, grid, (int)D, grid);
     return clipa_check_launch("layernorm_bwd_reduce");
   }
-  float* part2 = part + (size_t)2 * grid * D;
+  float* part2 = part + (size_t)NA * grid * D;
   const int per = (grid + LN_BWD_SLICES - 1) / LN_BWD_SLICES;
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cols, LN_BWD_SLICES), dim3(256), 0, st, part, part2, part2 + (size_t)LN_BWD_SLICES * D, grid, (int)D, per);
+  LN_REDUCE(dim3(cols, LN_BWD_SLICES), part, part2, part2 + (size_t)LN_BWD_SLICES * D, part2 + (size_t)2 * LN_BWD_SLICES * D, grid, (int)D, per);
   if (int rc = clipa_check_launch("layernorm_bwd_reduce")) return rc;
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cols), dim3(256), 0, st, part2, dgamma, dbeta, LN_BWD_SLICES, (int)D, LN_BWD_SLICES);
+  LN_REDUCE(dim3(cols), part2, dgamma, dbeta, colsum, LN_BWD_SLICES, (int)D, LN_BWD_SLICES);
+#undef LN_REDUCE
   return clipa_check_launch("layernorm_bwd_reduce2");
 }
 }  // namespace
+
+extern "C" int clipa_layernorm_bwd_q8(const void* x, const float* gamma, const float* beta, const void* dy, const void* dres,
+                                      void* dx, void* y, void* q, float* dq, float* colsum, float* rownorm, float* dgamma,
+                                      float* dbeta, int64_t rows, int64_t D, float eps, int fmt, void* workspace,
+                                      int64_t workspace_bytes, void* stream) {
+  if (fmt != 0 && fmt != 1) { clipa_set_error("layernorm_bwd_q8: fmt must be 0 (e4m3) or 1 (e5m2)"); return CLIPA_ERR_ARG; }
+  if (!q || !dq || !colsum) { clipa_set_error("layernorm_bwd_q8: q, dq and colsum are required"); return CLIPA_ERR_ARG; }
+  if ((beta == nullptr) != (y == nullptr)) { clipa_set_error("layernorm_bwd_q8: beta and y go together"); return CLIPA_ERR_ARG; }
+  return ln_bwd_impl(x, gamma, beta, dy, dres, dx, y, dgamma, dbeta, rows, D, eps, 0, 0, workspace, workspace_bytes, stream, fmt, q, dq, colsum, rownorm);
+}

@@ -235,6 +235,30 @@ def _fp8_fill(x, kept, P, cfg):
     return (h1, qkv, a, stats, x1, h2, hpre, g)
 
 
+# The LayerNorm-1 backward of block i writes dx = the gradient block i-1 receives - and, in fp8 mode, that gradient's row-quantised
+# form with its column sums (ops.layernorm_bwd(q8_fmt=...)): block i-1's backward starts from exactly that (its c_proj products
+# and bias gradient).  The autograd edge between two ResBlockFn nodes carries one tensor, so the operand travels beside it: one
+# slot, taken (and cleared) by the next fp8 block backward that runs.  The slot holds dx itself, so its memory cannot be
+# recycled while the offer stands: a gradient that arrives with dx's address, shape and version IS dx (a summed or copied
+# gradient is another allocation and is quantised the ordinary way).
+_Q8_HANDOFF = []
+
+
+def _q8_offer(dx, q8, fmt):
+    _Q8_HANDOFF[:] = [(dx, fmt, q8)]
+
+
+def _q8_take(dy, fmt):
+    slot = _Q8_HANDOFF[:]
+    del _Q8_HANDOFF[:]
+    if slot:
+        dx, f, q8 = slot[0]
+        if f == fmt and dy.data_ptr() == dx.data_ptr() and dy.shape == dx.shape and dy.stride() == dx.stride() \
+                and dy.dtype == dx.dtype and dy._version == dx._version:
+            return q8
+    return None
+
+
 def _block_backward_fp8(x, dy, box, P, cfg, scales):
     """Backward of a block in fp8 mode: every matrix product - input gradients AND (round 6) weight gradients - on
     v_mfma_f32_16x16x128_f8f6f4.  Each incoming gradient is quantised once per token (its column sums = the bias gradient ride
@@ -246,7 +270,7 @@ def _block_backward_fp8(x, dy, box, P, cfg, scales):
     dy = dy.contiguous()
     fmt = cfg.get("fp8_grad_fmt", ops.FMT_E4M3)
     # y = x1 + c_proj(gelu(hpre))
-    dq, ds, d_b_proj, rn = ops.quantize_rows(dy, fmt, want_colsum=True, want_rownorm=True)
+    dq, ds, d_b_proj, rn = _q8_take(dy, fmt) or ops.quantize_rows(dy, fmt, want_colsum=True, want_rownorm=True)
     emit_g = (lambda r, t: ops.scale_quantize_rows(g, r, t)) if g is not None else (lambda r, t: ops.scale_quantize_rows(hpre, r, t, act=act))
     d_w_proj = _wgrad8(dq, ds, sg, emit_g, P["dt_w_proj"], cfg)
     del g
@@ -267,10 +291,10 @@ def _block_backward_fp8(x, dy, box, P, cfg, scales):
     d_w_fc = _wgrad8(dq, ds, s2, emit_h2, P["dt_w_fc"], cfg)
     dh2 = _dlin8(dq, ds, P, "fc", cfg)                                            # [M,D]
     del dq, ds, h2
-    dx1, d_ln2_w, d_ln2_b = ops.layernorm_bwd(x1, P["ln2_w"], dh2, dres=dy, eps=eps)
+    # (round 6) the two LayerNorm backwards hand the next product its fp8 operand themselves: the rows are in registers
+    dx1, d_ln2_w, d_ln2_b, (dq, ds, d_b_out) = ops.layernorm_bwd(x1, P["ln2_w"], dh2, dres=dy, eps=eps, q8_fmt=fmt)
     del dh2, x1
     # x1 = x + out_proj(a)
-    dq, ds, d_b_out = _gradq8(dx1, cfg)
     d_w_out = _wgrad8(dq, ds, sa, lambda r, t: ops.scale_quantize_rows(a, r, t), P["dt_w_out"], cfg)
     da = _dlin8(dq, ds, P, "out", cfg)
     del dq, ds
@@ -283,7 +307,11 @@ def _block_backward_fp8(x, dy, box, P, cfg, scales):
     d_w_in = _wgrad8(dq, ds, s1, emit_h1, P["dt_w_in"], cfg)
     dh1 = _dlin8(dq, ds, P, "in", cfg)
     del dq, ds, h1
-    dx, d_ln1_w, d_ln1_b = ops.layernorm_bwd(x, P["ln1_w"], dh1, dres=dx1, eps=eps)
+    if cfg.get("q8_handoff"):      # the block in front of this one runs the same engine: its backward starts from (q, dq, colsum, rownorm)
+        dx, d_ln1_w, d_ln1_b, q8 = ops.layernorm_bwd(x, P["ln1_w"], dh1, dres=dx1, eps=eps, q8_fmt=fmt, want_rownorm=True)
+        _q8_offer(dx, q8, fmt)
+    else:
+        dx, d_ln1_w, d_ln1_b = ops.layernorm_bwd(x, P["ln1_w"], dh1, dres=dx1, eps=eps)
     return dx, (d_ln1_w, d_ln1_b, d_w_in, d_b_in, d_w_out, d_b_out, d_ln2_w, d_ln2_b, d_w_fc, d_b_fc, d_w_proj,
                 d_b_proj)
 

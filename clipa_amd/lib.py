@@ -28,6 +28,8 @@ SIGNATURES = {
     "clipa_layernorm_bwd_workspace": (_I64, [_I64, _I64]),
     "clipa_layernorm_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _F, _I32, _I32, _P, _I64, _P]),
     "clipa_layernorm_bwd_y": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _F, _I32, _I32, _P, _I64, _P]),
+    "clipa_layernorm_bwd_q8_workspace": (_I64, [_I64, _I64]),
+    "clipa_layernorm_bwd_q8": (_I32, [_P] * 13 + [_I64, _I64, _F, _I32, _P, _I64, _P]),
     "clipa_attention_fwd": (_I32, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I32, _P]),
     "clipa_attention_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I32, _P]),
     "clipa_attention_fwd_varlen": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I32, _P]),

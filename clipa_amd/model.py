@@ -194,6 +194,8 @@ class Transformer(nn.Module):
                 ks = frozenset(t for t, n in self.keep_counts.items() if i >= len(self.resblocks) - n) | engine.KEEP_SETS.get(cfg["keep"] if cfg is not base else None, frozenset())
                 if ks:
                     cfg = dict(base, keep_this=True, keep=ks)
+            if self.fp8 and i > 0:      # this block's LayerNorm-1 backward hands block i-1 its incoming gradient as fp8 operand
+                cfg = dict(cfg, q8_handoff=True)
             if i == last and pooled_rows is not None:
                 return engine.LastBlockFn.apply(x, pooled_rows, cfg, cache, *blk.param_tuple())
             x = engine.ResBlockFn.apply(x, cfg, cache, *blk.param_tuple())

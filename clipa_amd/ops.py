@@ -479,13 +479,40 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=None):
     return y
 
 
-def layernorm_bwd(x, gamma, dy, dres=None, eps=1e-5, beta=None):
+def layernorm_bwd(x, gamma, dy, dres=None, eps=1e-5, beta=None, q8_fmt=None, want_rownorm=False):
     """Returns dx (dtype of x, + dres if given), dgamma, dbeta (f32) - and, when `beta` is given, y = LayerNorm(x) (dtype of
-    dy) as a fourth value: bit for bit what layernorm_fwd returns, written by the pass that has the rows in registers anyway."""
+    dy) as a fourth value: bit for bit what layernorm_fwd returns, written by the pass that has the rows in registers anyway.
+    q8_fmt (FMT_E4M3 / FMT_E5M2; bf16 tensors): a last value (q, dq, colsum[, rownorm]) = quantize_rows(dx, q8_fmt, want_colsum=True
+    [, want_rownorm=True]) - the fp8 operand of the linear layer this gradient reaches next, from the same pass."""
     x = x.contiguous()
     dy = dy.contiguous()
     D = x.shape[-1]
     rows = x.numel() // D
+    if q8_fmt is not None:
+        _chk(x, bf16, "x")
+        _chk(dy, bf16, "dy")
+        if dres is not None:
+            dres = dres.contiguous()
+            _chk(dres, bf16, "dres")
+        wsb = lib.query("clipa_layernorm_bwd_q8_workspace", rows, D)
+        ws = torch.empty(max(wsb, 4) // 4, device=x.device, dtype=f32)
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(D, device=x.device, dtype=f32)
+        dbeta = torch.empty(D, device=x.device, dtype=f32)
+        q = torch.empty((rows, D), device=x.device, dtype=u8)
+        dq = torch.empty(rows, device=x.device, dtype=f32)
+        cs = torch.empty(D, device=x.device, dtype=f32)
+        rn = torch.empty(rows, device=x.device, dtype=f32) if want_rownorm else None
+        y = None
+        if beta is not None:
+            _chk(beta, f32, "beta", 1)
+            y = torch.empty(x.shape, device=x.device, dtype=bf16)
+        nbytes = float(rows) * D * (7 + (2 if dres is not None else 0) + (2 if y is not None else 0))
+        with _Timed("ln_bwd", 0.0, nbytes, f"{rows},{D},+q8{',+y' if y is not None else ''}"):
+            lib.call("clipa_layernorm_bwd_q8", _p(x), _p(gamma), _p(beta), _p(dy), _p(dres), _p(dx), _p(y), _p(q), _p(dq), _p(cs), _p(rn),
+                     _p(dgamma), _p(dbeta), rows, D, float(eps), int(q8_fmt), _p(ws), wsb, _stream())
+        q8 = (q, dq, cs, rn) if want_rownorm else (q, dq, cs)
+        return (dx, dgamma, dbeta, y, q8) if y is not None else (dx, dgamma, dbeta, q8)
     wsb = lib.query("clipa_layernorm_bwd_workspace", rows, D)
     ws = torch.empty(max(wsb, 4) // 4, device=x.device, dtype=f32)
     dx = torch.empty_like(x)

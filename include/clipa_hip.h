@@ -158,6 +158,14 @@ int clipa_layernorm_bwd(const void* x, const float* gamma, const void* dy, const
 int clipa_layernorm_bwd_y(const void* x, const float* gamma, const float* beta, const void* dy, const void* dres, void* dx,
                           void* y, float* dgamma, float* dbeta, int64_t rows, int64_t D, float eps, int x_f32,
                           int y_f32, void* workspace, int64_t workspace_bytes, void* stream);
+/* fp8 engine (no reference counterpart, as the clipa_quantize_rows family above): the bf16 LayerNorm backward that also hands
+ * the linear layer in front of it its incoming gradient as fp8 operand - q uint8 [rows, D] (fmt 0 = e4m3, 1 = e5m2), dq f32 [rows]
+ * (bit for bit what clipa_quantize_rows makes of the bf16 dx this call writes), colsum f32 [D] = sum over rows of dx (that
+ * layer's bias gradient), rownorm f32 [rows] (optional: ||dx[r,:]||_2).  beta / y: NULL, or both given as in clipa_layernorm_bwd_y. */
+int64_t clipa_layernorm_bwd_q8_workspace(int64_t rows, int64_t D);
+int clipa_layernorm_bwd_q8(const void* x, const float* gamma, const float* beta, const void* dy, const void* dres, void* dx, void* y,
+                           void* q, float* dq, float* colsum, float* rownorm, float* dgamma, float* dbeta, int64_t rows, int64_t D,
+                           float eps, int fmt, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* softmax(q.k^T * scale + mask).v per (batch, head); q/k/v are column blocks of the packed projection
  * output (row stride ld_qkv), out is [B*L, H*dh] (row stride ld_o). causal = additive triu(1)*-inf mask.

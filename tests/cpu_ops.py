@@ -139,7 +139,10 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=None):
     return O.layer_norm(x.float(), gamma, beta, eps).to(out_dtype or x.dtype)
 
 
-def layernorm_bwd(x, gamma, dy, dres=None, eps=1e-5, beta=None):
+def layernorm_bwd(x, gamma, dy, dres=None, eps=1e-5, beta=None, q8_fmt=None, want_rownorm=False):
+    if q8_fmt is not None:
+        r = layernorm_bwd(x, gamma, dy, dres, eps, beta)
+        return (*r, quantize_rows(r[0].reshape(-1, x.shape[-1]), q8_fmt, want_colsum=True, want_rownorm=want_rownorm))
     xr = x.float().detach().requires_grad_(True)
     g = gamma.detach().clone().requires_grad_(True)
     b = torch.zeros_like(g, requires_grad=True)

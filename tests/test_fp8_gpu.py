@@ -614,3 +614,78 @@ def test_gemm_f8a_producer_quantised_outputs(act):
     scr, invr = o.row_bound(rnr, o.rownorm_max(wr), None, 1.13)
     qr = o.gemm_nt_f8(xrq, xrs, wrq, wrs, epi=o.EPI_ACT, act=act, out_scale=invr)
     assert torch.equal(qr, o.scale_quantize_rows(o.gemm_nt_f8(xrq, xrs, wrq, wrs, epi=o.EPI_ACT, act=act), invr, one))
+
+
+@pytest.mark.parametrize("rows,D,fmt", [(1000, 1280, 0), (4099, 1024, 0), (777, 768, 1), (300, 384, 0), (2048, 2048, 1)])
+def test_layernorm_bwd_with_quantised_output(rows, D, fmt):
+    """ops.layernorm_bwd(q8_fmt=...) (clipa_layernorm_bwd_q8, round 6: the LayerNorm backward that hands the next linear layer its
+    fp8 gradient operand): dx, dgamma, dbeta (and the emitted LayerNorm output) bit for bit those of the plain backward; q and
+    the row scales bit for bit clipa_quantize_rows of that dx; column sums and row norms equal to the quantiser's up to the order
+    of fp32 additions.  An all-zero gradient row (a padding token) gets scale 0 and zero bytes."""
+    o = ops()
+    g = torch.Generator().manual_seed(rows + D)
+    x = (torch.randn(rows, D, generator=g) * 2 + 0.3).to(bf16).to(DEV)
+    dy = (torch.randn(rows, D, generator=g) * 1e-2 * torch.exp(torch.randn(rows, 1, generator=g))).to(bf16).to(DEV)
+    dres = (torch.randn(rows, D, generator=g) * 1e-2).to(bf16).to(DEV)
+    x[5] = 0.0
+    dy[5] = 0.0
+    dres[5] = 0.0
+    gam = (1 + 0.1 * torch.randn(D, generator=g)).to(DEV)
+    bet = (0.1 * torch.randn(D, generator=g)).to(DEV)
+    for with_res in (True, False):
+        for with_y in (False, True):
+            ref = o.layernorm_bwd(x, gam, dy, dres=dres if with_res else None, beta=bet if with_y else None)
+            got = o.layernorm_bwd(x, gam, dy, dres=dres if with_res else None, beta=bet if with_y else None, q8_fmt=fmt, want_rownorm=True)
+            assert len(got) == len(ref) + 1
+            for a, b in zip(ref, got[:-1]):
+                assert torch.equal(a, b)
+            q, dq, cs, rn = got[-1]
+            q_ref, dq_ref, cs_ref, rn_ref = o.quantize_rows(ref[0], fmt, want_colsum=True, want_rownorm=True)
+            assert torch.equal(q, q_ref) and torch.equal(dq, dq_ref)
+            assert float(dq[5]) == 0.0 and int(q[5].to(torch.int32).abs().sum() & 0x7f) == 0
+            want = ref[0].double().sum(0)
+            scale = float(ref[0].double().abs().sum(0).max())
+            assert float((cs.double() - want).abs().max()) <= 1e-5 * scale
+            assert float((cs - cs_ref).abs().max()) <= 1e-5 * scale
+            assert torch.allclose(rn, rn_ref, rtol=1e-5, atol=1e-12)
+            again = o.layernorm_bwd(x, gam, dy, dres=dres if with_res else None, beta=bet if with_y else None, q8_fmt=fmt, want_rownorm=True)[-1]
+            assert all(torch.equal(a, b) for a, b in zip(got[-1], again))      # fixed-order reductions
+
+
+def test_fp8_block_chain_uses_the_handed_over_gradient_operand():
+    """Two fp8 blocks in a row: the second block's LayerNorm-1 backward offers its dx as fp8 operand (engine._q8_offer), the first
+    block's backward takes it instead of launching the row quantiser - same gradients as with the hand-off disabled (the bytes
+    and scales are identical; the bias gradient of c_proj differs by the order of fp32 additions only)."""
+    from clipa_amd import engine
+    torch.manual_seed(3)
+    from clipa_amd.model import Transformer
+    t = Transformer(256, 3, 4, mlp_ratio=4.0).to(DEV)
+    t.fp8 = True
+    cache = engine.WeightCache()
+    B, L = 8, 32
+    x0 = torch.randn(B * L, 256, device=DEV).to(bf16)
+
+    def run(handoff):
+        taken = []
+        real_take, real_offer = engine._q8_take, engine._q8_offer
+        engine._q8_take = lambda dy, fmt: (lambda r: (taken.append(r is not None), r)[1])(real_take(dy, fmt) if handoff else None)
+        engine._q8_offer = real_offer if handoff else (lambda *a: None)
+        try:
+            for p in t.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            y = t.run(x, B, L, False, cache)
+            (y.float() * torch.linspace(-1, 1, y.numel(), device=DEV).reshape(y.shape)).sum().backward()
+            return taken, x.grad.clone(), {n: p.grad.clone() for n, p in t.named_parameters()}
+        finally:
+            engine._q8_take, engine._q8_offer = real_take, real_offer
+    taken, gx, grads = run(True)
+    assert taken == [False, True, True], taken          # last block: nothing offered yet; blocks 1 and 0 start from the offer
+    taken0, gx0, grads0 = run(False)
+    assert taken0 == [False, False, False]
+    assert torch.equal(gx, gx0)
+    for n in grads:
+        if n.endswith("mlp.c_proj.bias"):
+            assert torch.allclose(grads[n].float(), grads0[n].float(), rtol=2e-2, atol=1e-6), n
+        else:
+            assert torch.equal(grads[n], grads0[n]), n

@@ -66,9 +66,11 @@ cases = {
     "ln_fwd_q8s": (lambda: ops.layernorm_fwd_q8s(x, gam, bet, ds, t), 3 * M * D),
     "ln_fwd": (lambda: ops.layernorm_fwd(x, gam, bet), 4 * M * D),
     "ln_bwd_dres": (lambda: ops.layernorm_bwd(x, gam, dy, dres=dy), 8 * M * D),
+    "ln_bwd_dres_q8": (lambda: ops.layernorm_bwd(x, gam, dy, dres=dy, q8_fmt=0, want_rownorm=True), 9 * M * D),
+    "quantize_rows_colsum_D": (lambda: ops.quantize_rows(dy, 0, want_colsum=True, want_rownorm=True), 3 * M * D),
 }
 for name, (fn, nbytes) in cases.items():
-    if args.only and args.only not in name:
+    if args.only and not any(o in name for o in args.only.split(",")):
         continue
     ms = timed(fn)
     print(json.dumps({"kernel": name, "rows": M, "D": D, "ms": round(ms, 4), "gbps": round(nbytes / ms * 1e-6), "lib": os.path.basename(lib.LIB_PATH)}), flush=True)
