@@ -377,7 +377,8 @@ def test_layernorm_row_counts(rows, D):
 # -------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dh", [64, 80])       # 80 = ViT-H/14 (head_width 80)
 @pytest.mark.parametrize("B,H,L,causal", [(2, 3, 26, False), (3, 2, 50, False), (2, 2, 77, True), (2, 4, 197, False),
-                                          (1, 2, 257, False), (2, 1, 8, True), (2, 2, 32, True), (1, 2, 288, True)])
+                                          (1, 2, 257, False), (2, 1, 8, True), (2, 2, 32, True), (1, 2, 288, True),
+                                          (3, 5, 257, False), (2, 2, 258, False), (2, 2, 257, True)])
 def test_attention(B, H, L, causal, dh):
     D = dh * H
     qkv = rnd(B * L, 3 * D, seed=30 + L, scale=1.2)
