@@ -358,7 +358,24 @@ def main():
     dist_on = world > 1 or os.environ.get("CLIPA_BENCH_FORCE_DIST") == "1"
     if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+        # RCCL prints a version banner ("RCCL version : ... Librccl path : ...") on the C stdout when its first communicator comes
+        # up - in front of the ONE JSON line this script owes its caller.  File descriptor 1 points at stderr while the group and
+        # its communicator are created (a first all-reduce forces the lazy part), then C's buffer is flushed and stdout restored.
+        import ctypes
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+            dist.all_reduce(torch.zeros(1, device=dev))
+            torch.cuda.synchronize()
+        finally:
+            try:
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     import clipa_amd
     from clipa_amd import ops
