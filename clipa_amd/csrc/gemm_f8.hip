@@ -227,7 +227,7 @@ namespace {
 int gemm_nt_f8_impl(const void* A8, const void* B8, const float* scale_a, const float* scale_b, void* C, void* C2, const float* bias,
                     const void* aux, const float* scale_out, float* colsum_partial, int outq, int64_t M, int64_t N, int64_t K,
                     int64_t lda, int64_t ldb, int64_t ldc, int64_t ldaux, float alpha, int epi, int act, int fmt_a, int fmt_b,
-                    void* stream);
+                    void* stream, const float* emit_t = nullptr);
 }
 
 extern "C" int clipa_gemm_nt_f8(const void* A8, const void* B8, const float* scale_a, const float* scale_b, void* C,
@@ -256,11 +256,25 @@ extern "C" int clipa_gemm_nt_f8q(const void* A8, const void* B8, const float* sc
                          epi, act, fmt_a, 0, stream);
 }
 
+// The GELU-backward input-gradient product from the kept e4m3 pre-activation (CLIPA_EPI_DACT8) that ALSO writes the activation
+// operand of the same layer's fp8 weight gradient: X8[m, n] = e4m3(act(aux8[m, n]) * scale_a[m] / t_dev[0]), uint8 [M, ldc] - the
+// bytes clipa_scale_quantize_rows_e4m3(aux8, scale_a, t_dev, act) writes (scale_a = the row scales of the gradient operand A8,
+// t = clipa_rowscale_max of them and the activation's forward scales), from the epilogue that reads aux8 anyway.  Whole tiles only.
+extern "C" int clipa_gemm_nt_f8_emit(const void* A8, const void* B8, const float* scale_a, const float* scale_b, void* C, void* X8,
+                                     const void* aux8, const float* t_dev, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                                     int64_t ldc, int64_t ldaux, int act, int fmt_a, void* stream) {
+  if (M <= 0 || N <= 0) return CLIPA_OK;
+  if (!scale_a || !X8 || !aux8 || !t_dev) { clipa_set_error("gemm_nt_f8_emit: scale_a, X8, aux8 and t are required"); return CLIPA_ERR_ARG; }
+  if (!f8a_eligible(M, N, K, 0)) { clipa_set_error("gemm_nt_f8_emit: whole-tile shapes only (M, N %% 256 == 0, K %% 256 == 0, K >= 512)"); return CLIPA_ERR_ARG; }
+  return gemm_nt_f8_impl(A8, B8, scale_a, scale_b, C, X8, nullptr, aux8, nullptr, nullptr, 0, M, N, K, lda, ldb, ldc, ldaux, 1.0f,
+                         CLIPA_EPI_DACT8, act, fmt_a, 0, stream, t_dev);
+}
+
 namespace {
 int gemm_nt_f8_impl(const void* A8, const void* B8, const float* scale_a, const float* scale_b, void* C, void* C2, const float* bias,
                     const void* aux, const float* scale_out, float* colsum_partial, int outq, int64_t M, int64_t N, int64_t K,
                     int64_t lda, int64_t ldb, int64_t ldc, int64_t ldaux, float alpha, int epi, int act, int fmt_a, int fmt_b,
-                    void* stream) {
+                    void* stream, const float* emit_t) {
   if (M <= 0 || N <= 0) return CLIPA_OK;
   if (K <= 0 || K % 16 != 0) { clipa_set_error("gemm_nt_f8: K=%ld must be a positive multiple of 16", (long)K); return CLIPA_ERR_ARG; }
   if (lda % 16 != 0 || ldb % 16 != 0) { clipa_set_error("gemm_nt_f8: lda, ldb must be multiples of 16 bytes"); return CLIPA_ERR_ARG; }
@@ -273,7 +287,7 @@ int gemm_nt_f8_impl(const void* A8, const void* B8, const float* scale_a, const 
   if ((pre8 || aux8) && !f8a_eligible(M, N, K, fmt_b)) { clipa_set_error("gemm_nt_f8: CLIPA_EPI_ACT_PRE8 / CLIPA_EPI_DACT8 need whole-tile shapes (M, N %% 256 == 0, K %% 256 == 0, K >= 512, e4m3 weights)"); return CLIPA_ERR_ARG; }
   if (pre8 && !C2) { clipa_set_error("gemm_nt_f8: CLIPA_EPI_ACT_PRE8 needs C2"); return CLIPA_ERR_ARG; }
   if ((epi == CLIPA_EPI_ADD || epi == CLIPA_EPI_DACT) && (!aux || ldaux % 8 != 0)) { clipa_set_error("gemm_nt_f8: epilogue %d needs aux with ldaux%%8==0", epi); return CLIPA_ERR_ARG; }
-  if (C2 && epi != CLIPA_EPI_ACT) { clipa_set_error("gemm_nt_f8: C2 (pre-activation copy) goes with CLIPA_EPI_ACT only"); return CLIPA_ERR_ARG; }
+  if (C2 && epi != CLIPA_EPI_ACT && !emit_t) { clipa_set_error("gemm_nt_f8: C2 (pre-activation copy) goes with CLIPA_EPI_ACT only"); return CLIPA_ERR_ARG; }
   if ((fmt_a != 0 && fmt_a != 1) || (fmt_b != 0 && fmt_b != 1)) { clipa_set_error("gemm_nt_f8: formats are 0 (e4m3) or 1 (e5m2)"); return CLIPA_ERR_ARG; }
   if (256 * lda >= (1L << 30) || 256 * ldb >= (1L << 30) || 256 * ldc * 2 >= (1L << 30) || 256 * ldaux * 2 >= (1L << 30)) { clipa_set_error("gemm_nt_f8: leading dimension too large"); return CLIPA_ERR_ARG; }
   int dev = 0;
@@ -294,7 +308,7 @@ int gemm_nt_f8_impl(const void* A8, const void* B8, const float* scale_a, const 
     b.A = a.A; b.B = a.B; b.C = a.C; b.C2 = a.C2; b.bias = a.bias; b.aux = a.aux; b.sa = a.sa; b.sb = a.sb;
     b.M = a.M; b.N = a.N; b.K = a.K; b.lda = a.lda; b.ldb = a.ldb; b.ldc = a.ldc; b.ldaux = a.ldaux;
     b.alpha = a.alpha; b.epi = a.epi; b.act = a.act; b.abl = a.abl; b.gm = a.gm; b.pre8 = pre8; b.aux8 = aux8;
-    b.so = scale_out; b.cs_part = colsum_partial; b.outq = outq;
+    b.so = scale_out; b.cs_part = colsum_partial; b.outq = outq; b.emit_t = emit_t;
     return f8a_launch(b, fmt_a, dev, num_cu, st);
   }
   note_gemm(7);

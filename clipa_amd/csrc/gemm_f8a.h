@@ -14,6 +14,8 @@ struct F8AArgs {
   const float* so;                      // OUTQ: per-row output scale [M] (the e4m3 output of row m is the bf16 result times so[m]); NULL = 1
   float* cs_part;                       // OUTQ == 2 (DACT): [M / 128][N] partial column sums of the unscaled outputs
   int outq;                             // C holds e4m3 bytes (1 byte per element, row stride ldc BYTES)
+  const float* emit_t;                  // CLIPA_EPI_DACT8 with the activation operand of the weight gradient as second output (round 6): C2 = uint8 [M, ldc],
+                                        // C2[m, n] = e4m3(act(aux[m, n]) * sa[m] / emit_t[0]) - what clipa_scale_quantize_rows_e4m3 writes; NULL = no such output
   int pre8, aux8;                       // C2 / aux hold e4m3 bytes (1 byte per element, row strides ldc / ldaux in BYTES): CLIPA_EPI_ACT_PRE8 / CLIPA_EPI_DACT8
 };
 

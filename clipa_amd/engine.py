@@ -271,10 +271,22 @@ def _block_backward_fp8(x, dy, box, P, cfg, scales):
     fmt = cfg.get("fp8_grad_fmt", ops.FMT_E4M3)
     # y = x1 + c_proj(gelu(hpre))
     dq, ds, d_b_proj, rn = _q8_take(dy, fmt) or ops.quantize_rows(dy, fmt, want_colsum=True, want_rownorm=True)
-    emit_g = (lambda r, t: ops.scale_quantize_rows(g, r, t)) if g is not None else (lambda r, t: ops.scale_quantize_rows(hpre, r, t, act=act))
-    d_w_proj = _wgrad8(dq, ds, sg, emit_g, P["dt_w_proj"], cfg)
+    # (round 6) the GELU-backward epilogue of the input-gradient GEMM reads the kept e4m3 pre-activation anyway: it also emits the
+    # activation operand of this layer's weight gradient (ops.gemm_nt_f8_emit) - the weight gradient then follows the input gradient
+    fuse_emit = g is None and hpre is not None and hpre.dtype == torch.uint8 and not (fmt == ops.FMT_E4M3 and cfg.get("fp8_predict"))
+    if not fuse_emit:
+        emit_g = (lambda r, t: ops.scale_quantize_rows(g, r, t)) if g is not None else (lambda r, t: ops.scale_quantize_rows(hpre, r, t, act=act))
+        d_w_proj = _wgrad8(dq, ds, sg, emit_g, P["dt_w_proj"], cfg)
     del g
-    if fmt == ops.FMT_E4M3 and cfg.get("fp8_predict"):
+    if fuse_emit:
+        t = ops.rowscale_max(ds, sg)
+        wq, ws = P["wt8_proj"]
+        dh, x8 = ops.gemm_nt_f8_emit(dq, ds, wq, ws, hpre, t, act=act, fmt_a=fmt)
+        d_w_proj = ops.gemm_tn_f8(dq, x8, t=t, fmt_p=fmt, out_dtype=P["dt_w_proj"])
+        del x8
+        dq, ds, d_b_fc = _gradq8(dh, cfg)
+        del dh
+    elif fmt == ops.FMT_E4M3 and cfg.get("fp8_predict"):
         # the gradient of the pre-activation leaves the GEMM as the e4m3 operand of the next two products, with its column sums
         # (the bias gradient of c_fc) from the same epilogue; row scale predicted as in the forward: |dh[m,c]| <=
         # ||dy[m,:]|| * max_c ||W_proj[:,c]|| * max gelu' (1.13), times 1.13 for the operands' rounding

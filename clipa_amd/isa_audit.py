@@ -72,7 +72,7 @@ def epilogue_store_counts(path, txt):
             return 32 * (2 if pre in (1, 3) else 1), 32 if pre == 2 else 0
         m = re.search(r"gemm_f8a_kernelILi(\d+)ELi(\d+)ELb([01])ELi(\d+)E", kname)
         pre, outq = (int(m.group(2)), int(m.group(4))) if m else (0, 0)
-        return 32 * ((pre == 1) + (outq == 0)), 32 * ((pre == 2) + (outq != 0))
+        return 32 * ((pre == 1) + (outq == 0)), 32 * ((pre in (2, 3)) + (outq != 0))
 
     def close_kernel():
         if kernel is not None and copies == 0:

@@ -65,6 +65,7 @@ SIGNATURES = {
     "clipa_quantize_rows_colsum": (_I32, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _P, _I64, _P]),
     "clipa_layernorm_fwd_q8n": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P]),
     "clipa_gemm_nt_f8q": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I32, _I32, _I32, _P]),
+    "clipa_gemm_nt_f8_emit": (_I32, [_P] * 8 + [_I64] * 7 + [_I32, _I32, _P]),
     "clipa_reduce_partial_rows": (_I32, [_P, _P, _I64, _I64, _P]),
     "clipa_rownorm_max": (_I32, [_P, _I64, _I64, _I64, _P, _P]),
     "clipa_absmax_f32": (_I32, [_P, _I64, _P, _P]),
@@ -134,7 +135,7 @@ def last_gemm():
 
 def gemm_counts(reset=False):
     """Launches per GEMM kernel family since the last reset (csrc/internal_hooks.h; tests only): list indexed like last_gemm(),
-    [10] / [11] gemm_nta with the e4m3 pre-activation copy / operand epilogue, [12] / [13] the same of gemm_f8a, [14] gemm_f8a with a producer-quantised (e4m3) output."""
+    [10] / [11] gemm_nta with the e4m3 pre-activation copy / operand epilogue, [12] / [13] the same of gemm_f8a, [14] gemm_f8a with a producer-quantised (e4m3) output, [15] gemm_nta's e4m3-operand GELU-backward that also writes the activation, [0] gemm_f8a's that also emits the weight gradient's activation operand."""
     fn = load().clipa_internal_gemm_counts
     fn.restype, fn.argtypes = _I32, [ctypes.POINTER(ctypes.c_long), _I32, _I32]
     buf = (ctypes.c_long * 16)()

@@ -262,6 +262,33 @@ def absmax(v):
     return out
 
 
+def gemm_nt_f8_emit(a8, sa, b8, sb, aux8, t, *, act=ACT_GELU_ERF, fmt_a=FMT_E4M3):
+    """EPI_DACT from the kept e4m3 pre-activation that also emits the activation operand of the same layer's fp8 weight gradient:
+    -> (C bf16 [M,N] = gemm_nt_f8(a8, sa, b8, sb, epi=EPI_DACT, aux=aux8), X8 uint8 [M,N] = scale_quantize_rows(aux8, sa, t, act=act)),
+    X8 written by the GEMM's epilogue on whole-tile shapes (clipa_gemm_nt_f8_emit), by the two separate launches otherwise."""
+    M, K = a8.shape
+    N = b8.shape[0]
+    if not (_whole_tiles_f8(M, N, K) and sa is not None):
+        return (gemm_nt_f8(a8, sa, b8, sb, None, epi=EPI_DACT, act=act, aux=aux8, fmt_a=fmt_a),
+                scale_quantize_rows(aux8, sa, t, act=act))
+    _chk(a8, u8, "a8", 2)
+    _chk(b8, u8, "b8", 2)
+    _chk(aux8, u8, "aux8", 2)
+    _chk(sa, f32, "sa", 1)
+    _chk(t, f32, "t")
+    a8, lda = _rowmajor(a8)
+    b8, ldb = _rowmajor(b8)
+    aux8, ldaux = _rowmajor(aux8)
+    if b8.shape[1] != K or tuple(aux8.shape) != (M, N) or sa.numel() != M or (sb is not None and sb.numel() != N):
+        raise RuntimeError("gemm_nt_f8_emit: shape mismatch")
+    out = torch.empty((M, N), device=a8.device, dtype=bf16)
+    x8 = torch.empty((M, N), device=a8.device, dtype=u8)
+    with _Timed("gemm_nt_f8", 2.0 * M * N * K, 1.0 * (M * K + N * K) + 4.0 * M * N, f"{M},{N},{K},epi3,aux8+emit"):
+        lib.call("clipa_gemm_nt_f8_emit", _p(a8), _p(b8), _p(sa), _p(sb), _p(out), _p(x8), _p(aux8), _p(t), M, N, K, lda, ldb, N, ldaux,
+                 act, int(fmt_a), _stream())
+    return out, x8
+
+
 def gemm_nt_f8(a8, sa, b8, sb, bias=None, *, epi=EPI_NONE, act=ACT_GELU_ERF, aux=None, alpha=1.0, want_pre=False,
                fmt_a=FMT_E4M3, fmt_b=FMT_E4M3, out_scale=None, want_colsum=False):
     """C[M,N] bf16 = epi(alpha * sa[m] * sb[n] * a8[M,K] @ b8[N,K]^T + bias); a8, b8 uint8 tensors of fp8 bytes.

@@ -102,6 +102,12 @@ int clipa_gemm_nt_f8q(const void* A8, const void* B8, const float* scale_a, cons
                       const float* bias, const void* aux, const float* scale_out, float* colsum_partial, int64_t M, int64_t N,
                       int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldaux, float alpha, int epi, int act, int fmt_a,
                       void* stream);
+/* CLIPA_EPI_DACT8 (C = bf16((A8 . B8^T) scale_a scale_b * act'(aux8))) that also writes the activation operand of the same layer's fp8
+ * weight gradient, X8[m, n] = e4m3(act(aux8[m, n]) * scale_a[m] / t_dev[0]) (uint8 [M, ldc]) - bit for bit what
+ * clipa_scale_quantize_rows_e4m3(aux8, scale_a, t_dev, ..., act) writes, from the epilogue that reads aux8 anyway.  Whole tiles only. */
+int clipa_gemm_nt_f8_emit(const void* A8, const void* B8, const float* scale_a, const float* scale_b, void* C, void* X8,
+                          const void* aux8, const float* t_dev, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                          int64_t ldc, int64_t ldaux, int act, int fmt_a, void* stream);
 int clipa_reduce_partial_rows(const float* partial, float* out, int64_t nrows, int64_t K, void* stream);
 /* The predicted row scales themselves: clipa_rownorm_max: out[0] = max_r ||w[r,:]||_2 (w bf16 [rows, K], row stride ld);
  * clipa_absmax_f32: out[0] = max |v[i]|; clipa_row_bound: bound = factor * rownorm[m] * wnorm[0] + bmax[0] (bmax NULL = 0) ->

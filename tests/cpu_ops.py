@@ -114,6 +114,10 @@ def layernorm_fwd_q8(x, gamma, beta, eps=1e-5, want_bf16=False, want_rownorm=Fal
     return r + (y.reshape(-1, y.shape[-1]).float().norm(dim=1),) if want_rownorm else r
 
 
+def gemm_nt_f8_emit(a8, sa, b8, sb, aux8, t, *, act=0, fmt_a=FMT_E4M3):
+    return gemm_nt_f8(a8, sa, b8, sb, None, epi=EPI_DACT, act=act, aux=aux8, fmt_a=fmt_a), scale_quantize_rows(aux8, sa, t, act=act)
+
+
 def gemm_nt_f8(a8, sa, b8, sb, bias=None, *, epi=EPI_NONE, act=0, aux=None, alpha=1.0, want_pre=False, fmt_a=FMT_E4M3,
                fmt_b=FMT_E4M3, out_scale=None, want_colsum=False):
     a = a8.view(_F8[fmt_a][0]).float() * (sa[:, None] if sa is not None else 1.0)

@@ -146,7 +146,7 @@ def test_f8a_isa_audit(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     a = subprocess.run([sys.executable, os.path.join(ROOT, "clipa_amd", "isa_audit.py"), str(asm)], capture_output=True, text=True)
     assert a.returncode == 0, a.stdout[-3000:]
-    assert len(re.findall(r"\.name:\s+\S*gemm_f8a_kernel", asm.read_text())) == 22      # 11 epilogue flavours (5 + the two e4m3 pre-activation ones + 4 with a producer-quantised output) x e4m3 / e5m2 A operand
+    assert len(re.findall(r"\.name:\s+\S*gemm_f8a_kernel", asm.read_text())) == 24      # 12 epilogue flavours (5 + the two e4m3 pre-activation ones + 4 with a producer-quantised output + the operand-emitting GELU-backward) x e4m3 / e5m2 A operand
 
 
 def test_audit_rejects_a_store_data_race(tmp_path):
