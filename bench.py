@@ -901,6 +901,10 @@ def main():
                          # the family by epilogue (epi0 plain / bias, 1 GELU, 1+pre8 GELU + e4m3 copy, 2 residual add, 3 GELU-backward,
                          # 3,aux8 the same from e4m3 bytes, 3,aux8+act ... also writing the re-materialised GELU output - an HBM-bound
                          # pass folded into that launch): TFLOP/s and ms per step
+                         # rocprofv3 lists every epilogue instantiation as a kernel of its own; the one with the most time (plain / bias):
+                         "dominant_instantiation": (lambda v: None if v is None else {
+                             "kernel": "gemm_nta_kernel<CLIPA_EPI_NONE> (plain / bias launches)", "achieved": round(v["work"] / max(v["ms"], 1e-9) / 1e9, 1),
+                             "frac": round(v["work"] / max(v["ms"], 1e-9) / 1e9 / peak, 4), "launches": v["launches"]})(prof.get("gemm_nt#epi0")) if dom == "gemm_nt" else None,
                          "by_epilogue": {k[8:]: {"tflops": round(v["work"] / max(v["ms"], 1e-9) / 1e9, 1), "ms_per_step": round(v["ms"] / args.steps, 2),
                                                   "launches_per_step": v["launches"] // args.steps}
                                          for k, v in sorted(prof.items()) if k.startswith("gemm_nt#")} if dom == "gemm_nt" else None},
