@@ -369,8 +369,11 @@ int ln_fwd_grid(long rows) {
 #define LN_BWD_PERSISTENT_BLOCKS 1024         // A/B knob (tools/stream8_bench.py --lib): blocks of the persistent grid (rows wider than 1024)
 #endif
 constexpr int LN_BWD_SLICES = 16;
+#ifndef LN_BWD_CHUNK_MAXD
+#define LN_BWD_CHUNK_MAXD 1024                // A/B knob: widest row that takes the adjacent-rows grid
+#endif
 int ln_bwd_chunk(long rows, long D) {
-  if (D > 1024) return 0;
+  if (D > LN_BWD_CHUNK_MAXD) return 0;
   long c = (rows / 2048 + 3) / 4 * 4;
   return (int)(c < 4 ? 4 : (c > 128 ? 128 : c));
 }
