@@ -706,6 +706,7 @@ def test_production_kernels_end_to_end(name):
     print(f"[{name}] launches: gemm_nt2 {counts[1]}, gemm_nta {counts[2]} (e4m3 copy {counts[10]}, e4m3 operand {counts[11]}), "
           f"gemm_tn2 {counts[3]}, gemm_tn3 {counts[4]}, gemm_tna {counts[5]}")
     assert counts[2] >= 2 * 10 and counts[10] == 2 and counts[11] == 2, counts
+    assert counts[15] == 2, counts          # ... both with the activation output beside the gradient (round 6: no activation_fwd pass)
     # (the B-row products of LastBlockFn and the heads - M = 256 rows - and slice shapes with an odd number of K steps stay on gemm_tn2/3)
     assert counts[5] >= 6, counts
     ocfg = O.oracle_cfg(cfg)
