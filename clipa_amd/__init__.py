@@ -14,4 +14,4 @@ from .data import DeviceAugment, DevicePrefetcher
 from .transform import AugmentationCfg, image_transform
 from .zero import ShardedAdamW
 
-__version__ = "0.3.0"
+__version__ = "0.4.0"
