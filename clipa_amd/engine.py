@@ -245,16 +245,16 @@ _Q8_HANDOFF = []
 
 
 def _q8_offer(dx, q8, fmt):
-    _Q8_HANDOFF[:] = [(dx, fmt, q8)]
+    _Q8_HANDOFF[:] = [(dx, dx._version, fmt, q8)]
 
 
 def _q8_take(dy, fmt):
     slot = _Q8_HANDOFF[:]
     del _Q8_HANDOFF[:]
     if slot:
-        dx, f, q8 = slot[0]
+        dx, version, f, q8 = slot[0]
         if f == fmt and dy.data_ptr() == dx.data_ptr() and dy.shape == dx.shape and dy.stride() == dx.stride() \
-                and dy.dtype == dx.dtype and dy._version == dx._version:
+                and dy.dtype == dx.dtype and dy._version == version:      # (the version at the offer: an in-place hook would move it)
             return q8
     return None
 

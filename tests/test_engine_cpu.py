@@ -304,3 +304,29 @@ def test_encode_entry_points(golden):
     assert (i - golden.t("image_features")).abs().max() < 2e-2 and (t - golden.t("text_features")).abs().max() < 2e-2
     with pytest.raises(RuntimeError):
         m.encode_text(golden.texts[:, :-1])
+
+
+def test_fp8_gradient_operand_handoff_slot():
+    """engine._q8_offer / _q8_take (round 6): the row-quantised form of a block's input gradient travels beside the tensor to the
+    backward of the block in front of it.  It is taken only by the very next fp8 block backward and only for the SAME tensor - same
+    storage, shape, strides, dtype, version - in the same gradient format; a copy, a modified tensor or a later backward gets
+    nothing and quantises the ordinary way."""
+    from clipa_amd import engine
+    dx = torch.randn(8, 16).to(torch.bfloat16)
+    q8 = ("q", "dq", "colsum", "rownorm")
+    engine._q8_offer(dx, q8, 0)
+    assert engine._q8_take(dx, 0) is q8
+    assert engine._q8_take(dx, 0) is None                      # one slot, cleared by the take
+    engine._q8_offer(dx, q8, 0)
+    assert engine._q8_take(dx.clone(), 0) is None              # another allocation (a summed / copied gradient)
+    assert engine._q8_take(dx, 0) is None                      # ... and the miss cleared the slot too
+    engine._q8_offer(dx, q8, 0)
+    assert engine._q8_take(dx, 1) is None                      # other gradient format
+    engine._q8_offer(dx, q8, 0)
+    dx.add_(1)                                                 # modified in place after the offer: version counter moved
+    assert engine._q8_take(dx, 0) is None
+    engine._q8_offer(dx, q8, 0)
+    assert engine._q8_take(dx[:4], 0) is None                  # a view of a part: same address, other shape
+    engine._q8_offer(dx, q8, 0)
+    assert engine._q8_take(dx.view(8, 16), 0) is q8            # the same rows through another wrapper object
+    assert engine._Q8_HANDOFF == []
